@@ -1,0 +1,164 @@
+/*
+ * prt.h -- C ABI of libprt: the MI355X-native drop-in for the OpenCL enqueue sequence of the
+ * reference renderer (Mourtz/Photorealistic-Rendering-using-OpenCL, src/main.cpp).
+ *
+ * The reference has no plugin interface for its radiance loop; the boundary is the sequence of
+ * OpenCL host calls in src/main.cpp.  Each entry point below replaces one group of those calls
+ * (file:line given per function) with the same ownership rule the reference uses
+ * (CL_MEM_COPY_HOST_PTR, include/CL/cl_help.h:196-202): the caller keeps ownership of every host
+ * array, the library copies on upload.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Threading: one context per device; calls on one context are not re-entrant (the reference is
+ * single-threaded with an in-order queue and a finish() after every enqueue).  Contexts on
+ * different devices may be driven from different threads/processes.
+ *
+ * Errors: every function returns PRT_OK (0) or a negative prt_status; prt_last_error() gives a
+ * message.  The library never aborts or exits (the reference prints and exit(1)s,
+ * include/CL/cl_kernel.h:22-28).  There is NO CPU fallback: without a HIP device prt_create fails.
+ */
+#ifndef PRT_H
+#define PRT_H
+
+#include <stdint.h>
+#include "prt_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PRT_ABI_VERSION 1
+#define PRT_MAX_LIGHTS 16
+
+typedef enum prt_status {
+    PRT_OK = 0,
+    PRT_ERR_INVALID_ARGUMENT = -1,
+    PRT_ERR_NO_DEVICE = -2,
+    PRT_ERR_HIP = -3,
+    PRT_ERR_NOT_READY = -4,     /* scene / camera / size not set before rendering */
+    PRT_ERR_UNSUPPORTED = -5    /* scene needs a feature outside the hot-path scope (SDF, box) */
+} prt_status;
+
+/* phase function of the global medium.  The reference wires Isotropic at source level
+ * (kernels/media.cl:61); HG (g fixed 0.6, kernels/phasefunctions/HenyeyGreenstein.cl:4) and
+ * Rayleigh exist as files.  Here it is a run-time choice. */
+typedef enum prt_phase { PRT_PHASE_ISOTROPIC = 0, PRT_PHASE_HG = 1 } prt_phase;
+
+/*
+ * The scene-specialisation parameters of the reference's kernel builder
+ * (include/CL/cl_kernel.h:13-446 substitutes them into kernels/header.cl:39-122 as #defines).
+ */
+typedef struct prt_config {
+    uint32_t abi_version;            /* PRT_ABI_VERSION */
+    int32_t max_bounces;             /* cl_kernel.h:115-122   MAX_BOUNCES            (default 12) */
+    int32_t max_diff_bounces;        /* :124-131              MAX_DIFF_BOUNCES       (4)  */
+    int32_t max_spec_bounces;        /* :133-140              MAX_SPEC_BOUNCES       (4)  */
+    int32_t max_trans_bounces;       /* :142-149              MAX_TRANS_BOUNCES      (12) */
+    int32_t max_scattering_events;   /* :151-158              MAX_SCATTERING_EVENTS  (12) */
+    int32_t marching_steps;          /* :160-167  accepted, unused: SDF primitives are out of scope */
+    int32_t shadow_marching_steps;   /* :169-176  accepted, unused */
+    uint32_t active_mats;            /* :226-345  ACTIVE_MATS: OR of all material type bits in the scene */
+    uint32_t geom_flags;             /* :180-222  PRT_GEOM_* bits for H_SPHERE/H_BOX/H_SDF/H_QUAD */
+    uint32_t light_count;            /* :367-400  LIGHT_COUNT */
+    uint32_t light_indices[PRT_MAX_LIGHTS]; /*   LIGHT_INDICES (only [0] is ever sampled, base.cl:92) */
+    int32_t has_global_medium;       /* :47-54    GLOBAL_MEDIUM */
+    float fog_density;               /* :66-75    values AFTER the "%f" round trip of std::to_string */
+    float fog_sigma_a;               /* :77-84 */
+    float fog_sigma_s;               /* :86-93 */
+    float fog_sigma_t;               /* :95-102 */
+    int32_t fog_abs_only;            /* :104-111 */
+    int32_t alpha_testing;           /* :56-63    -alpha */
+    int32_t phase_function;          /* prt_phase */
+    float phase_g;                   /* HG asymmetry; the reference fixes 0.6 */
+} prt_config;
+
+/* Host buffers of one scene, in the reference's layouts (src/main.cpp:93-122,401-418). */
+typedef struct prt_scene_desc {
+    const prt_mesh* meshes;          /* cl_meshes  src/main.cpp:418: order spheres, sdfs, boxes, quads */
+    uint32_t object_count[8];        /* kernel arg 3 (cl_uint8): n_sphere,n_sdf,n_box,n_quad,_,_,_,total  include/Scene/scene.h:20-22 */
+    const prt_material* obj_material;/* mBufMaterial src/main.cpp:403-404: ONE material for the whole OBJ (may be NULL if no OBJ) */
+    const float* vertices;           /* mBufVertices :117  float4[3*T], de-indexed, xyz used */
+    const float* normals;            /* mBufNormals  :118  float4[3*T] */
+    const uint64_t* primitive_indices;/* mNewBufIndices :119 cl_ulong[T] */
+    uint32_t triangle_count;         /* T */
+    const prt_bvh_node* bvh_nodes;   /* mNewBufBVH :412   node 0 = root */
+    uint32_t bvh_node_count;
+} prt_scene_desc;
+
+typedef struct prt_stats {
+    double kernel_ms;        /* device time of the render kernels of the last prt_render_* call (HIP events on the context's stream) */
+    uint32_t launches;       /* kernel launches in that call */
+    uint32_t frames;         /* frames (= segments per live pixel) executed in that call */
+    uint64_t samples;        /* sum over pixels of RLH.samples (paths started)   -- filled by prt_query_counts */
+    uint64_t segments;       /* sum over pixels of acc.w (segments executed)     -- filled by prt_query_counts */
+    uint64_t finished_pixels;/* pixels frozen by the spp rule                     -- filled by prt_query_counts */
+} prt_stats;
+
+typedef struct prt_ctx prt_ctx;
+
+/* initOpenCL(), src/main.cpp:124-209 + cl_help::kernel::parse: pick the device and specialise
+ * the integrator for one scene.  `device` is a HIP device ordinal. */
+int prt_create(int device, const prt_config* cfg, prt_ctx** out);
+
+/* process exit in the reference; explicit here. */
+void prt_destroy(prt_ctx* ctx);
+
+/* clw::buffer::create x5 + mBufMaterial, src/main.cpp:401-418,93-122.  Copies and re-packs. */
+int prt_upload_scene(prt_ctx* ctx, const prt_scene_desc* scene);
+
+/* enqueueWriteBuffer(cl_camera), src/main.cpp:294-297 (every frame in the reference). */
+int prt_set_camera(prt_ctx* ctx, const prt_camera* cam);
+
+/* cl_env_map, src/main.cpp:433-437 + include/GL/cl_gl_interop.h:71-86: RGB float, row 0 first.
+ * Without a call the map is a 1x1 black texel. */
+int prt_upload_envmap(prt_ctx* ctx, const float* rgb, int width, int height);
+
+/* cl_flattenI = W*H*112 bytes, src/main.cpp:451; output texture tex0.  Implies prt_reset. */
+int prt_resize(prt_ctx* ctx, int width, int height);
+
+/* Multi-GPU row tile: this context renders rows [row0, row0+rows) of the width x full_height
+ * image; seeds and camera use GLOBAL pixel coordinates so the union of tiles is bit-identical to
+ * a single-context render.  State/framebuffer calls then address the tile only.  Implies reset. */
+int prt_set_tile(prt_ctx* ctx, int width, int full_height, int row0, int rows);
+
+/* buffer_reset branch of render(), src/main.cpp:283-291: zero the path state. */
+int prt_reset(prt_ctx* ctx);
+
+/* setArg(4,++framenumber); setArg(6,rand()); setArg(7,rand()); enqueueNDRangeKernel; finish --
+ * src/main.cpp:299-304,260-261 -- batched: frames first_frame .. first_frame+n-1 (frame numbers
+ * start at 1), seed_pairs = {random0, random1} per frame.  Every pixel advances one path segment
+ * per frame.  Asynchronous on the context's stream; prt_synchronize / any read waits. */
+int prt_render_frames(prt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, const int32_t* seed_pairs);
+
+/* "N spp": frames 1,2,... with a pixel frozen once its N-th path has terminated
+ * (reset && samples == spp).  Runs until every pixel is frozen or max_frames frames were used;
+ * seed_pairs must hold max_frames pairs.  *frames_used (optional) receives the frame count of
+ * the slowest pixel.  Requires a freshly reset context. */
+int prt_render_spp(prt_ctx* ctx, uint32_t spp, uint32_t max_frames, const int32_t* seed_pairs,
+                   uint32_t* frames_used);
+
+int prt_synchronize(prt_ctx* ctx);
+
+/* output texture: linear float4 acc/samples per pixel, row 0 = top (kernels/main.cl:159). */
+int prt_read_framebuffer(prt_ctx* ctx, float* rgba);
+/* same, device to device, into caller-owned device memory (e.g. a torch tensor) on the context's stream */
+int prt_copy_framebuffer_to_device(prt_ctx* ctx, void* device_rgba);
+
+/* r_flat, in the reference's 112-byte RTD layout (checkpoint / resume / parity checks). */
+int prt_read_state(prt_ctx* ctx, prt_path_state* state);
+int prt_write_state(prt_ctx* ctx, const prt_path_state* state);
+
+/* run on a caller-provided hipStream_t (NULL = the context's own stream) */
+int prt_set_stream(prt_ctx* ctx, void* hip_stream);
+
+int prt_get_stats(prt_ctx* ctx, prt_stats* stats);
+/* device-side reduction of samples / segments / frozen pixels (fills those prt_stats fields) */
+int prt_query_counts(prt_ctx* ctx, uint32_t spp, prt_stats* stats);
+
+const char* prt_last_error(prt_ctx* ctx);
+/* message for a failed prt_create (ctx == NULL) */
+const char* prt_last_global_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PRT_H */

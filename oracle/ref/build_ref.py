@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""oracle/ref/build_ref.py -- TEST INFRASTRUCTURE: recipe that builds the REFERENCE's own code
+for this path from the sources where they lie under /root/reference.  Outputs go only to
+oracle/_ref/ (git-ignored binaries) -- no reference text is written into the repository; the
+scene-specialised kernel text lives in a temp directory for the duration of the compile.
+
+What gets built
+  oracle/_ref/ref_host            reference host code: include/Scene/scene.h (JSON loader),
+                                  include/CL/cl_kernel.h (kernel specialiser), Camera
+                                  (+ oracle/ref/ref_host.cpp, a 90-line driver)
+  oracle/_ref/libref_<variant>.so reference device code: kernels/main.cl and everything it
+                                  #FILE-includes, specialised for one scene by the reference's
+                                  own cl_kernel.h::parse, compiled as OpenCL C for x86-64 by
+                                  ROCm clang, linked with oracle/ref/clrt_shim.cpp (OpenCL C
+                                  runtime: work-item/image functions + built-in math =
+                                  include/prt_detmath.h) and oracle/ref/ref_harness.cpp.
+  <blob_dir>/<variant>.sceneblob  the host buffers the reference loader produced (fixture data)
+
+Known, documented interventions:
+  Q1  '#FILE:bxdf/materials/..' is lower-case, the directory is 'Materials': resolved through
+      a symlink farm in the temp dir (the reference only runs on case-insensitive file systems).
+  Q9  the any-hit traversal stack has 8 entries and no overflow check (kernels/geometry/bvh.cl:
+      42-44,97): `--shadow-stack N` rewrites that one `#define STACK_SIZE 8` in the TEMP text so
+      the host run cannot smash its stack.  Results are identical whenever the original would
+      not have overflowed.
+  C99 `inline` functions without an external definition (kernels/bxdf/Fresnel.cl:33) are
+      compiled with -Dinline= so they get one.
+"""
+import argparse
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+OUT = os.path.join(ROOT, "oracle", "_ref")
+CLANG = "/opt/rocm/lib/llvm/bin/clang"
+CLANGXX = "/opt/rocm/lib/llvm/bin/clang++"
+MARCH = "-march=x86-64-v3"
+
+
+def run(cmd, **kw):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, **kw)
+    if r.returncode != 0:
+        sys.stderr.write("FAILED: %s\n%s\n" % (" ".join(cmd), r.stdout[-4000:]))
+        raise SystemExit(1)
+    return r.stdout
+
+
+def make_farm(tmp):
+    """symlink farm: <tmp>/kernels mirrors /root/reference/kernels, plus lower-case aliases."""
+    kroot = os.path.join(tmp, "kernels")
+    src = os.path.join(REF, "kernels")
+    for d, dirs, files in os.walk(src):
+        rel = os.path.relpath(d, src)
+        os.makedirs(os.path.join(kroot, rel), exist_ok=True)
+        for f in files:
+            os.symlink(os.path.join(d, f), os.path.join(kroot, rel, f))
+    for d, dirs, files in os.walk(kroot):
+        for sub in list(dirs):
+            low = sub.lower()
+            if low != sub and not os.path.exists(os.path.join(d, low)):
+                os.symlink(os.path.join(d, sub), os.path.join(d, low))
+    os.makedirs(os.path.join(tmp, "run"), exist_ok=True)
+
+
+def build_host():
+    os.makedirs(OUT, exist_ok=True)
+    exe = os.path.join(OUT, "ref_host")
+    run(["g++", "-std=c++17", "-O1", "-w", "-I%s/include" % REF, "-I%s/external" % REF,
+         "-I/opt/rocm/include", os.path.join(HERE, "ref_host.cpp"),
+         os.path.join(REF, "src/Camera/camera.cpp"), "-o", exe, "-lOpenCL"])
+    return exe
+
+
+def build_support(tmp):
+    objs = []
+    for src in ("clrt_shim.cpp", "ref_harness.cpp"):
+        o = os.path.join(tmp, src + ".o")
+        run([CLANGXX, "-std=c++17", "-O2", "-ffp-contract=off", MARCH, "-fPIC", "-I%s/include" % ROOT,
+             "-c", os.path.join(HERE, src), "-o", o])
+        objs.append(o)
+    return objs
+
+
+def build_variant(name, scene, width, height, alpha, shadow_stack, phase, blob_dir, exe, tmp, support):
+    cl = os.path.join(tmp, name + ".cl")
+    blob = os.path.join(blob_dir, name + ".sceneblob")
+    run([exe, os.path.abspath(scene), str(width), str(height), "1" if alpha else "0", cl, blob],
+        cwd=os.path.join(tmp, "run"))
+    if shadow_stack or phase:
+        text = open(cl).read()
+        if shadow_stack:
+            needle = "#define STACK_SIZE 8\n"
+            assert text.count(needle) == 1, "shadow stack define not found exactly once"
+            text = text.replace(needle, "#define STACK_SIZE %d\n" % shadow_stack)
+        open(cl, "w").write(text)
+    obj = os.path.join(tmp, name + ".o")
+    run([CLANG, "-x", "cl", "-cl-std=CL1.2", "-Xclang", "-finclude-default-header",
+         "-target", "x86_64-unknown-linux-gnu", MARCH, "-O2", "-ffp-contract=off", "-fPIC",
+         "-Wno-error=incompatible-pointer-types", "-w", "-Dinline=", "-c", cl, "-o", obj])
+    os.remove(cl)
+    so = os.path.join(OUT, "libref_%s.so" % name)
+    run([CLANGXX, "-shared", "-o", so, obj] + support + ["-Wl,--no-undefined", "-lpthread", "-lm"])
+    return so
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--variant", action="append", default=[],
+                    help="name=scene.json (repeatable)")
+    ap.add_argument("--width", type=int, default=64)
+    ap.add_argument("--height", type=int, default=64)
+    ap.add_argument("--alpha", action="store_true")
+    ap.add_argument("--shadow-stack", type=int, default=64)
+    ap.add_argument("--phase", default="", help="(reserved) phase-function variant")
+    ap.add_argument("--blob-dir", default=os.path.join(ROOT, "tests", "golden"))
+    a = ap.parse_args()
+    if not os.path.isdir(REF):
+        print("reference not present: nothing to build (the GPU box uses the prebuilt files)")
+        return 0
+    exe = build_host()
+    tmp = tempfile.mkdtemp(prefix="prt_ref_")
+    try:
+        make_farm(tmp)
+        support = build_support(tmp)
+        for v in a.variant:
+            name, scene = v.split("=", 1)
+            so = build_variant(name, scene, a.width, a.height, a.alpha, a.shadow_stack, a.phase,
+                               a.blob_dir, exe, tmp, support)
+            print("built", so)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

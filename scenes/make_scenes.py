@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Generates the benchmark / parity scene files of BASELINE.json's configs.
+
+The Cornell-box layout (one sphere light, six quads, one OBJ) is the one the reference's
+scenes/cornell.json describes; the files are generated from the parameters below rather than
+copied, and the per-config differences are the ones SURVEY §8d lists:
+  cornell_coat        config 1: teapot COAT (type 4) roughness 0.1, Beckmann        (= reference cornell.json)
+  cornell_diffuse     config 2: teapot DIFF (type 1)  -> ACTIVE_MATS = LIGHT|DIFF
+  cornell_roughcond   config 3a: teapot ROUGH_COND (type 10), GGX (dist 2), roughness 0.1
+  cornell_roughdiel   config 3b: teapot ROUGH_DIEL (type 11), GGX, roughness 0.1, + one small DIEL sphere
+  cornell_media       config 4: global medium density 0.07 sigmaA 0 sigmaS 1, teapot DIFF, light (0,1.5,-1) r 0.2 L 34
+  cornell_dragon      config 5: procedural ~870k-triangle stand-in mesh (dragon.obj is not available)
+"""
+import json
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+WHITE = [1.0, 1.0, 1.0]
+
+
+def quad(base, e0, e1, color):
+    return {"vertices": base + e0 + e1, "material": {"color": color}}
+
+
+def box_quads():
+    return [
+        quad([0.0, 0.0, 0.0], [4.0, 0.0, 0.0], [0.0, 0.0, 4.0], WHITE),      # ceiling-side plane y=0 facing -y
+        quad([0.0, 4.0, 0.0], [-4.0, 0.0, 0.0], [0.0, 0.0, 4.0], WHITE),
+        quad([0.0, 2.0, 2.0], [4.0, 0.0, 0.0], [0.0, 4.0, 0.0], WHITE),
+        quad([0.0, 2.0, -2.0], [-4.0, 0.0, 0.0], [0.0, 4.0, 0.0], WHITE),
+        quad([2.0, 2.0, 0.0], [0.0, 4.0, 0.0], [0.0, 0.0, 4.0], [0.8, 0.1, 0.1]),
+        quad([-2.0, 2.0, 0.0], [0.0, -4.0, 0.0], [0.0, 0.0, 4.0], [0.1, 0.8, 0.1]),
+    ]
+
+
+def settings(b=32, d=8, s=32, t=64, sc=128):
+    return {"MAX_BOUNCES": b, "MAX_DIFF_BOUNCES": d, "MAX_SPEC_BOUNCES": s, "MAX_TRANS_BOUNCES": t,
+            "MAX_SCATTERING_EVENTS": sc, "MARCHING_STEPS": 128, "SHADOW_MARCHING_STEPS": 64}
+
+
+def cornell(obj_material, obj="teapot.obj", extra_spheres=(), light=None, medium=None, st=None):
+    light = light or {"pos": [0.0, 3.0, 0.0], "radius": 0.5, "material": {"color": [5.0, 5.0, 5.0], "type": 0}}
+    doc = {}
+    if medium:
+        doc["global_medium"] = medium
+    doc["settings"] = st or settings()
+    doc["scene"] = {"obj": {"path": obj, "material": obj_material},
+                    "spheres": [light] + list(extra_spheres), "quads": box_quads()}
+    return doc
+
+
+SCENES = {
+    "cornell_coat": cornell({"color": WHITE, "type": 4, "roughness": 0.1}),
+    "cornell_diffuse": cornell({"color": WHITE, "type": 1}),
+    "cornell_roughcond": cornell({"color": WHITE, "type": 10, "dist": 2, "roughness": 0.1}),
+    "cornell_roughdiel": cornell({"color": WHITE, "type": 11, "dist": 2, "roughness": 0.1},
+                                 extra_spheres=[{"pos": [1.2, 0.4, 0.8], "radius": 0.4,
+                                                 "material": {"color": WHITE, "type": 3}}]),
+    "cornell_media": cornell({"color": WHITE, "type": 1},
+                             light={"pos": [0.0, 1.5, -1.0], "radius": 0.2,
+                                    "material": {"color": [34.0, 34.0, 34.0], "type": 0}},
+                             medium={"density": 0.07, "sigmaA": 0.0, "sigmaS": 1.0},
+                             st=settings(12, 4, 16, 32, 1024)),
+    "cornell_dragon": cornell({"color": WHITE, "type": 1}, obj="dragon_standin.prtmesh"),
+}
+
+if __name__ == "__main__":
+    for name, doc in SCENES.items():
+        with open(os.path.join(HERE, name + ".json"), "w") as f:
+            json.dump(doc, f, separators=(",", ":"))
+            f.write("\n")
+        print("wrote", name)
