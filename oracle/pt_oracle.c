@@ -1,0 +1,1232 @@
+/*
+ * oracle/pt_oracle.c -- TEST INFRASTRUCTURE.  Plain-C CPU restatement of the reference's radiance
+ * loop (kernels/main.cl render_kernel and everything it includes).  It is the checker the
+ * product (the HIP path behind include/prt.h) is compared with, and the timed CPU baseline of
+ * bench.py.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it;
+ * the product never links or calls anything in oracle/.
+ *
+ * Pinned by: oracle/_ref (the reference's own kernel text compiled for the host in the
+ * development container) -- tests/test_oracle_vs_ref.py demands bit-identical path state and
+ * framebuffer on every scene variant -- and by the golden fixtures under tests/golden/ produced
+ * by that reference build.
+ *
+ * Each function cites the reference file:line it follows.  Where the reference is a
+ * compile-time variant (#ifdef on the scene's ACTIVE_MATS etc., include/CL/cl_kernel.h) the
+ * same decision is taken at run time from prt_config.  Built-in math is include/prt_detmath.h
+ * (the stated OpenCL built-in library of this project); vector expressions are evaluated
+ * component-wise, left to right, one rounding per operation, never contracted
+ * (compile with -ffp-contract=off).
+ *
+ * Quirks reproduced on purpose: Q2 sphere light direction, Q3/Q13 left-to-right
+ * RNG draws, Q4 light sampled from the probe ray's hit point, Q6 zero guard mesh for OBJ hits,
+ * Q7 LambertBSDF_pdf == 0 (what clang makes of the missing return), Q8 medium channel lane 3,
+ * Q11 INF = 20, Q14 seed derivation, Q15 no pixel jitter, Q19 acc.w counts segments; and the
+ * TempRay {time,dist} swap of kernels/main.cl:27-28.
+ */
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "prt.h"
+#include "prt_detmath.h"
+#include "pt_oracle.h"
+
+#define EPS 1e-5f                         /* kernels/header.cl:4 */
+#define INF 2e1f                          /* kernels/header.cl:5 */
+#define PI 3.1415926535897932384626433832795f
+#define TWO_PI 6.283185307179586476925286766559f
+#define INV_PI 0.3183098861837906715377675267450f
+#define INV_TWO_PI 0.1591549430918953357688837633725f
+#define INV_FOUR_PI 0.0795774715459476678844418816863f
+
+typedef struct { float x, y, z; } v3;
+
+static inline v3 V(float x, float y, float z) { v3 r = {x, y, z}; return r; }
+static inline v3 vsplat(float s) { return V(s, s, s); }
+static inline v3 vadd(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 vsub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 vmul(v3 a, v3 b) { return V(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline v3 vscale(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
+static inline v3 vdivs(v3 a, float s) { return V(a.x / s, a.y / s, a.z / s); }
+static inline v3 vneg(v3 a) { return V(-a.x, -a.y, -a.z); }
+static inline float vdot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline v3 vcross(v3 a, v3 b) { return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+static inline float vlength(v3 a) { return prt_sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+static inline v3 vnormalize(v3 a) { float inv = 1.0f / prt_sqrt(a.x * a.x + a.y * a.y + a.z * a.z); return V(a.x * inv, a.y * inv, a.z * inv); }
+static inline v3 vload(const float* p) { return V(p[0], p[1], p[2]); }
+static inline float fmax3(v3 v) { return prt_fmax(prt_fmax(v.x, v.y), v.z); }       /* kernels/utils.cl:29 */
+static inline float avg3(v3 v) { return (v.x * 1.0f + v.y * 1.0f + v.z * 1.0f) * 0.3333333333333333333333333333333333333333333333f; } /* utils.cl:37 */
+static inline v3 vexp(v3 a) { return V(prt_exp(a.x), prt_exp(a.y), prt_exp(a.z)); }
+
+/* ---- kernels/header.cl:154-170 Ray, :172-204 TangentFrame, :208-215 SurfaceScatterEvent ---- */
+typedef struct {
+    v3 origin, dir, normal, pos;
+    float t;
+    int backside;
+    float time;
+} Ray;
+
+typedef struct { v3 normal, tangent, bitangent; } TangentFrame;
+
+typedef struct {
+    v3 wi, wo, weight;
+    float pdf;
+    uint8_t requestedLobe, sampledLobe;
+    TangentFrame frame;
+} SurfaceScatterEvent;
+
+typedef struct { v3 d; float dist, pdf; } LightSample;                 /* header.cl:263-268 */
+typedef struct { v3 w, weight; float pdf; } PhaseSample;               /* media.cl:4-8 */
+typedef struct { v3 p; float continuedT; v3 continuedWeight; float t; v3 weight; float pdf; int exited; } MediumSample; /* media.cl:10-19 */
+
+typedef struct { unsigned s0, s1; } Rng;
+
+typedef struct {
+    const prt_config* cfg;
+    const prt_mesh* meshes;         /* meshes[-1] is a zeroed guard (Q6) */
+    const uint32_t* counts;
+    const uint64_t* indices;
+    const float* vertices;
+    const float* normals;
+    const prt_material* obj_mat;
+    const prt_bvh_node* nodes;
+    const float* env; int env_w, env_h;
+    int nTransMask;                 /* DIEL|ROUGH_DIEL bits that are compiled in (intersect.cl:222-230) */
+    int max_stack, max_shadow_stack;/* diagnostics */
+} Scene;
+
+/* ---- kernels/prng/prng.cl:5-16 ---- */
+static inline float next1D(Rng* r) {
+    r->s0 = 36969u * (r->s0 & 65535u) + (r->s0 >> 16);
+    r->s1 = 18000u * (r->s1 & 65535u) + (r->s1 >> 16);
+    unsigned ires = (r->s0 << 16) + r->s1;
+    return (prt_u2f((ires & 0x007fffffu) | 0x40000000u) - 2.0f) * 0.5f;
+}
+
+/* ---- kernels/header.cl:179-204 ---- */
+static TangentFrame createTangentFrame(v3 n) {
+    TangentFrame f;
+    float sn = prt_copysign(1.0f, n.z);
+    float a = -1.0f / (sn + n.z);
+    float b = n.x * n.y * a;
+    f.normal = n;
+    f.tangent = V(1.0f + sn * n.x * n.x * a, sn * b, -sn * n.x);
+    f.bitangent = V(b, sn + n.y * n.y * a, -n.y);
+    return f;
+}
+static inline v3 toLocal(const TangentFrame* f, v3 p) { return V(vdot(f->tangent, p), vdot(f->bitangent, p), vdot(f->normal, p)); }
+static inline v3 toGlobal(const TangentFrame* f, v3 p) {
+    return vadd(vadd(vscale(f->tangent, p.x), vscale(f->bitangent, p.y)), vscale(f->normal, p.z));
+}
+
+/* ---- kernels/utils.cl:92-152 sampling warps ---- */
+static v3 uniformSphere(float xi_x, float xi_y) {
+    float phi = xi_x * TWO_PI;
+    float z = xi_y * 2.0f - 1.0f;
+    float r = prt_sqrt(prt_fmax(1.0f - z * z, 0.0f));
+    return V(prt_cos(phi) * r, prt_sin(phi) * r, z);
+}
+static v3 uniformSphericalCap(float xi_x, float xi_y, float cosThetaMax) {
+    float phi = xi_x * TWO_PI;
+    float z = xi_y * (1.0f - cosThetaMax) + cosThetaMax;
+    float r = prt_sqrt(prt_fmax(1.0f - z * z, 0.0f));
+    return V(prt_cos(phi) * r, prt_sin(phi) * r, z);
+}
+static v3 cosineHemisphere(float xi_x, float xi_y) {
+    float phi = xi_x * TWO_PI;
+    float r = prt_sqrt(xi_y);
+    return V(prt_cos(phi) * r, prt_sin(phi) * r, prt_sqrt(prt_fmax(1.0f - xi_y, 0.0f)));
+}
+static inline float cosineHemispherePdf(v3 p) { return prt_fabs(p.z) * INV_PI; }
+static inline int checkReflectionConstraint(v3 wi, v3 wo) {            /* utils.cl:50-52 */
+    return prt_fabs(wi.z * wo.z - wi.x * wo.x - wi.y * wo.y - 1.0f) < 1e-3f;
+}
+static inline int checkRefractionConstraint(v3 wi, v3 wo, float eta, float cosThetaT) { /* utils.cl:54-58 */
+    float dotP = -wi.x * wo.x * eta - wi.y * wo.y * eta - prt_copysign(cosThetaT, wi.z) * wo.z;
+    return prt_fabs(dotP - 1.0f) < 1e-3f;
+}
+
+/* ---- kernels/camera.cl:17-66 ---- */
+static Ray createCamRay(int cx, int cy, int width, int height, const prt_camera* cam, Rng* rng) {
+    v3 view = vnormalize(vload(cam->view));
+    v3 up = vnormalize(vload(cam->up));
+    v3 horizontalAxis = vnormalize(vcross(view, up));
+    v3 verticalAxis = vnormalize(vcross(horizontalAxis, view));
+    v3 position = vload(cam->position);
+    v3 middle = vadd(position, view);
+    v3 horizontal = vscale(horizontalAxis, prt_tan(cam->fov[0] * 0.5f * (PI / 180)));
+    v3 vertical = vscale(verticalAxis, prt_tan(cam->fov[1] * -0.5f * (PI / 180)));
+    int pixelx = cx;
+    int pixely = height - cy - 1;
+    float sx = (float)pixelx / (width - 1.0f);
+    float sy = (float)pixely / (height - 1.0f);
+    v3 pointOnPlane = vadd(vadd(middle, vscale(horizontal, (2 * sx) - 1)), vscale(vertical, (2 * sy) - 1));
+    v3 pointOnImagePlane = vadd(position, vscale(vsub(pointOnPlane, position), cam->focalDistance));
+    v3 aperturePoint;
+    if (cam->apertureRadius > 0.00001f) {
+        float random1 = next1D(rng);
+        float random2 = next1D(rng);
+        float angle = 2 * PI * random1;
+        float distance = cam->apertureRadius * prt_sqrt(random2);
+        float apertureX = prt_cos(angle) * distance;
+        float apertureY = prt_sin(angle) * distance;
+        aperturePoint = vadd(vadd(position, vscale(horizontalAxis, apertureX)), vscale(verticalAxis, apertureY));
+    } else {
+        aperturePoint = position;
+    }
+    Ray ray;
+    memset(&ray, 0, sizeof(ray));
+    ray.backside = 0;
+    ray.origin = aperturePoint;
+    ray.dir = vnormalize(vsub(pointOnImagePlane, aperturePoint));
+    ray.time = next1D(rng);
+    return ray;
+}
+
+/* ---- kernels/geometry/triangle.cl:4-43 ---- */
+static int intersectTriangle(const Scene* sc, Ray* ray, uint32_t fIndex) {
+    const uint32_t fv = (uint32_t)sc->indices[fIndex] * 3u;
+    const v3 p0 = vload(sc->vertices + 4 * (size_t)(fv + 0));
+    const v3 p1 = vload(sc->vertices + 4 * (size_t)(fv + 1));
+    const v3 p2 = vload(sc->vertices + 4 * (size_t)(fv + 2));
+    const v3 e1 = vsub(p0, p1);
+    const v3 e2 = vsub(p2, p0);
+    const v3 n = vcross(e1, e2);
+    v3 c = vsub(p0, ray->origin);
+    v3 r = vcross(ray->dir, c);
+    float inv_det = prt_recip(vdot(n, ray->dir));
+    float u = vdot(r, e2) * inv_det;
+    float v = vdot(r, e1) * inv_det;
+    float w = 1.0f - u - v;
+    if (u >= 0 && v >= 0 && w >= 0) {
+        float t = vdot(n, c) * inv_det;
+        if (t > EPS && t < ray->t) {
+            ray->t = t;
+            const v3 n0 = vload(sc->normals + 4 * (size_t)(fv + 0));
+            const v3 n1 = vload(sc->normals + 4 * (size_t)(fv + 1));
+            const v3 n2 = vload(sc->normals + 4 * (size_t)(fv + 2));
+            ray->normal = vadd(vadd(vscale(n0, w), vscale(n1, u)), vscale(n2, v));
+            return 1;
+        }
+    }
+    return 0;
+}
+
+/* ---- kernels/geometry/bvh.cl:4-26 ---- */
+typedef struct { float inv[3], so[3]; int oct[3]; } RayPre;
+static RayPre ray_pre(const Ray* ray) {
+    RayPre p;
+    p.inv[0] = prt_recip(ray->dir.x); p.inv[1] = prt_recip(ray->dir.y); p.inv[2] = prt_recip(ray->dir.z);
+    p.so[0] = -ray->origin.x * p.inv[0]; p.so[1] = -ray->origin.y * p.inv[1]; p.so[2] = -ray->origin.z * p.inv[2];
+    p.oct[0] = ray->dir.x < 0.0f; p.oct[1] = ray->dir.y < 0.0f; p.oct[2] = ray->dir.z < 0.0f;
+    return p;
+}
+static inline void intersectNode(const prt_bvh_node* node, const RayPre* p, float ray_t, float* entry, float* exit_) {
+    float entry0 = prt_fma(node->bounds[0 * 2 + p->oct[0]], p->inv[0], p->so[0]);
+    float entry1 = prt_fma(node->bounds[1 * 2 + p->oct[1]], p->inv[1], p->so[1]);
+    float entry2 = prt_fma(node->bounds[2 * 2 + p->oct[2]], p->inv[2], p->so[2]);
+    float exit0 = prt_fma(node->bounds[0 * 2 + 1 - p->oct[0]], p->inv[0], p->so[0]);
+    float exit1 = prt_fma(node->bounds[1 * 2 + 1 - p->oct[1]], p->inv[1], p->so[1]);
+    float exit2 = prt_fma(node->bounds[2 * 2 + 1 - p->oct[2]], p->inv[2], p->so[2]);
+    *entry = prt_fmax(entry0, prt_fmax(entry1, prt_fmax(entry2, EPS)));
+    *exit_ = prt_fmin(exit0, prt_fmin(exit1, prt_fmin(exit2, ray_t)));
+}
+
+#define PTO_STACK 256
+/* kernels/geometry/bvh.cl:117-206 (closest hit) and :28-114 (any hit), one body */
+static int traverse_any(Scene* sc, Ray* ray, int any_hit) {
+    const prt_bvh_node* stack[PTO_STACK];
+    int stackSize = 0, maxStack = 0;
+    const prt_bvh_node* node = &sc->nodes[0];
+    const RayPre pre = ray_pre(ray);
+    if (node->is_leaf) {
+        int res = 0;
+        for (uint32_t i = node->first_child_or_primitive; i < node->first_child_or_primitive + node->primitive_count; ++i) {
+            int h = intersectTriangle(sc, ray, i);
+            if (h && any_hit) return 1;
+            res |= h;
+        }
+        return res;
+    }
+    for (;;) {
+        uint32_t first_child = node->first_child_or_primitive;
+        const prt_bvh_node* child[2] = { &sc->nodes[first_child + 0], &sc->nodes[first_child + 1] };
+        float entry[2], exit_[2];
+        intersectNode(child[0], &pre, ray->t, &entry[0], &exit_[0]);
+        intersectNode(child[1], &pre, ray->t, &entry[1], &exit_[1]);   /* both boxes use ray->t BEFORE either leaf is tested */
+        int go[2];
+        for (int k = 0; k < 2; ++k) {
+            go[k] = 1;
+            if (entry[k] <= exit_[k]) {
+                if (child[k]->is_leaf) {
+                    uint32_t b = child[k]->first_child_or_primitive, e = b + child[k]->primitive_count;
+                    if (any_hit) {
+                        for (uint32_t i = b; i < e; ++i) if (intersectTriangle(sc, ray, i)) return 1;
+                    } else {
+                        int res = 0;
+                        for (uint32_t i = b; i < e; ++i) res |= intersectTriangle(sc, ray, i);
+                        if (res && ray->t <= EPS) return 1;
+                    }
+                    go[k] = 0;
+                }
+            } else {
+                go[k] = 0;
+            }
+        }
+        if (go[0] ^ go[1]) {
+            node = go[0] ? child[0] : child[1];
+        } else if (go[0] & go[1]) {
+            const prt_bvh_node *l = child[0], *r = child[1];
+            if (entry[0] > entry[1]) { l = child[1]; r = child[0]; }
+            if (stackSize < PTO_STACK) stack[stackSize] = r;
+            ++stackSize;
+            if (stackSize > maxStack) maxStack = stackSize;
+            node = l;
+        } else {
+            if (stackSize == 0) break;
+            node = stack[--stackSize];
+        }
+    }
+    if (any_hit) { if (maxStack > sc->max_shadow_stack) sc->max_shadow_stack = maxStack; }
+    else if (maxStack > sc->max_stack) sc->max_stack = maxStack;
+    return 0;
+}
+
+/* ---- kernels/geometry/sphere.cl:5-41 ---- */
+static int intersect_sphere(Ray* ray, const prt_mesh* sphere) {
+    v3 p = vsub(ray->origin, vload(sphere->pos));
+    float B = vdot(p, ray->dir);
+    float radius = sphere->joker[0];
+    float C = vdot(p, p) - radius * radius;
+    float detSq = B * B - C;
+    if (detSq >= 0.0f) {
+        float det = prt_sqrt(detSq);
+        float t = -B - det;
+        if (t < ray->t && t > EPS) { ray->t = t; return 1; }
+        t = -B + det;
+        if (t < ray->t && t > EPS) { ray->t = t; return 1; }
+    }
+    return 0;
+}
+/* sphere.cl:59-63 */
+static float sphere_directPdf(const prt_mesh* sphere, v3 p) {
+    float dist = vlength(vsub(vload(sphere->pos), p));
+    float radius = sphere->joker[0];
+    float cosTheta = prt_sqrt(prt_fmax(dist * dist - radius * radius, 0.0f)) / dist;
+    return INV_TWO_PI / (1.0f - cosTheta);
+}
+/* sphere.cl:65-88 (Q2: the returned direction is toGlobal(frame, (float3)(cosTheta))) */
+static int sphere_sampleDirect(const prt_mesh* sphere, v3 p, LightSample* s, Rng* rng) {
+    v3 L = vsub(vload(sphere->pos), p);
+    float d = vlength(L);
+    float radius = sphere->joker[0];
+    float C = d * d - radius * radius;
+    if (C <= 0.0f) return 0;
+    L = vnormalize(L);
+    float cosTheta = prt_sqrt(C) / d;
+    float xi_x = next1D(rng), xi_y = next1D(rng);
+    v3 cap = uniformSphericalCap(xi_x, xi_y, cosTheta);
+    float B = d * cap.z;
+    float det = prt_sqrt(prt_fmax(B * B - C, 0.0f));
+    s->dist = B - det;
+    TangentFrame frame = createTangentFrame(L);
+    s->d = toGlobal(&frame, vsplat(cosTheta));
+    s->pdf = INV_TWO_PI / (1.0f - cosTheta);
+    return 1;
+}
+
+/* ---- kernels/geometry/quad.cl:11-62 ---- */
+static int intersect_quad(const prt_mesh* plane, Ray* ray) {
+    const v3 base = vload(plane->joker + 0), edge0 = vload(plane->joker + 3), edge1 = vload(plane->joker + 6), normal = vload(plane->joker + 9);
+    float nDotW = vdot(normal, ray->dir);
+    if (nDotW < 1e-5) return 0;                 /* double literal in the reference: a double comparison */
+    v3 anchor = vsub(base, vscale(vadd(edge0, edge1), 0.5f));
+    float rt = vdot(normal, vsub(anchor, ray->origin)) / nDotW;
+    if (rt <= EPS || rt >= ray->t) return 0;
+    v3 q = vadd(ray->origin, vscale(ray->dir, rt));
+    v3 v = vsub(q, anchor);
+    float l0 = vdot(v, edge0) / vdot(edge0, edge0);
+    float l1 = vdot(v, edge1) / vdot(edge1, edge1);
+    if (l0 < 0.0f || l0 > 1.0f || l1 < 0.0f || l1 > 1.0f) return 0;
+    ray->backside = 0;
+    ray->normal = normal;
+    ray->pos = q;
+    ray->t = rt;
+    return 1;
+}
+static int quad_sampleDirect(const prt_mesh* plane, v3 p, LightSample* s, Rng* rng) {
+    const v3 base = vload(plane->joker + 0), edge0 = vload(plane->joker + 3), edge1 = vload(plane->joker + 6), normal = vload(plane->joker + 9);
+    const float area = plane->joker[12];
+    if (vdot(normal, vsub(p, base)) <= 0.0f) return 0;
+    float xi_x = next1D(rng), xi_y = next1D(rng);
+    v3 q = vadd(vadd(base, vscale(edge0, xi_x)), vscale(edge1, xi_y));
+    s->d = vsub(q, p);
+    float rSq = vdot(s->d, s->d);
+    s->dist = prt_sqrt(rSq);
+    s->d = vdivs(s->d, s->dist);
+    float cosTheta = -vdot(normal, s->d);
+    s->pdf = rSq / (cosTheta * area);
+    return 1;
+}
+static float quad_directPdf(v3 dir, const prt_mesh* plane, v3 p) {
+    const v3 base = vload(plane->joker + 0), normal = vload(plane->joker + 9);
+    const float area = plane->joker[12];
+    float cosTheta = prt_fabs(vdot(normal, dir));
+    float t = vdot(normal, vsub(base, p)) / vdot(normal, dir);
+    return t * t / (cosTheta * area);
+}
+
+/* ---- kernels/geometry/geometry.cl:11-52 ---- */
+static int sampleDirect(const Scene* sc, const prt_mesh* mesh, v3 p, LightSample* s, Rng* rng) {
+    if ((sc->cfg->geom_flags & PRT_GEOM_SPHERE) && (mesh->t & PRT_GEOM_SPHERE)) return sphere_sampleDirect(mesh, p, s, rng);
+    else if ((sc->cfg->geom_flags & PRT_GEOM_QUAD) && (mesh->t & PRT_GEOM_QUAD)) return quad_sampleDirect(mesh, p, s, rng);
+    return 0;
+}
+static float directPdf(const Scene* sc, const prt_mesh* mesh, v3 dir, v3 p) {
+    if ((sc->cfg->geom_flags & PRT_GEOM_SPHERE) && (mesh->t & PRT_GEOM_SPHERE)) return sphere_directPdf(mesh, p);
+    else if ((sc->cfg->geom_flags & PRT_GEOM_QUAD) && (mesh->t & PRT_GEOM_QUAD)) return quad_directPdf(dir, mesh, p);
+    return 0.0f;
+}
+
+/* ---- kernels/intersect.cl:158-236 ---- */
+static int intersect_scene(Scene* sc, Ray* ray, int* mesh_id) {
+    ray->t = INF;
+    *mesh_id = -1;
+    traverse_any(sc, ray, 0);                                   /* always (Q10) */
+    ray->normal = vnormalize(ray->normal);
+    ray->pos = vadd(ray->origin, vscale(ray->dir, ray->t));
+    if (sc->cfg->geom_flags & PRT_GEOM_SPHERE) {
+        for (uint32_t i = 0; i < sc->counts[0]; ++i) {
+            const prt_mesh* sphere = &sc->meshes[i];
+            if (intersect_sphere(ray, sphere)) {
+                ray->pos = vadd(ray->origin, vscale(ray->dir, ray->t));
+                ray->normal = vnormalize(vsub(ray->pos, vload(sphere->pos)));
+                *mesh_id = (int)i;
+            }
+        }
+    }
+    /* boxes: geometry/box.cl is never #FILE-included, so __BOX__ is never defined (geometry.cl:4-9);
+     * scenes with boxes or SDFs are rejected by pto_render */
+    if (sc->cfg->geom_flags & PRT_GEOM_QUAD) {
+        uint32_t fl = sc->counts[0] + sc->counts[1];
+        for (uint32_t i = 0; i < sc->counts[3]; ++i) {
+            if (intersect_quad(&sc->meshes[fl], ray)) *mesh_id = (int)fl;
+            ++fl;
+        }
+    }
+    int nTrans = 1;
+    if (sc->nTransMask) nTrans = (sc->meshes[*mesh_id].mat.t & ~sc->nTransMask) != 0;
+    ray->backside = vdot(ray->normal, ray->dir) > 0.0f;
+    if (nTrans && ray->backside) ray->normal = vneg(ray->normal);
+    return ray->t < INF;
+}
+
+/* ---- kernels/intersect.cl:94-152 ---- */
+static int shadow(Scene* sc, Ray* ray) {
+    const float maxDist = ray->t;
+    Ray temp_ray = *ray;
+    if (traverse_any(sc, ray, 1)) { *ray = temp_ray; return 0; }
+    if (sc->cfg->geom_flags & PRT_GEOM_SPHERE) {
+        for (uint32_t i = 0; i < sc->counts[0]; ++i)
+            if (intersect_sphere(ray, &sc->meshes[i])) { if (ray->t < maxDist) return 0; }
+    }
+    uint32_t fl = sc->counts[0] + sc->counts[1];
+    if (sc->cfg->geom_flags & PRT_GEOM_QUAD) {
+        for (uint32_t i = 0; i < sc->counts[3]; ++i)
+            if (intersect_quad(&sc->meshes[fl++], ray)) { if (ray->t < maxDist) return 0; }
+    }
+    return 1;
+}
+
+/* ---- kernels/bxdf/Fresnel.cl:6-67 ---- */
+static float conductorReflectance(float eta, float k, float cosThetaI) {
+    float cosThetaISq = cosThetaI * cosThetaI;
+    float sinThetaISq = prt_fmax(1.0f - cosThetaISq, 0.0f);
+    float sinThetaIQu = sinThetaISq * sinThetaISq;
+    float innerTerm = eta * eta - k * k - sinThetaISq;
+    float aSqPlusBSq = prt_sqrt(prt_fmax(innerTerm * innerTerm + 4.0f * eta * eta * k * k, 0.0f));
+    float a = prt_sqrt(prt_fmax((aSqPlusBSq + innerTerm) * 0.5f, 0.0f));
+    float Rs = ((aSqPlusBSq + cosThetaISq) - (2.0f * a * cosThetaI)) / ((aSqPlusBSq + cosThetaISq) + (2.0f * a * cosThetaI));
+    float Rp = ((cosThetaISq * aSqPlusBSq + sinThetaIQu) - (2.0f * a * cosThetaI * sinThetaISq)) /
+               ((cosThetaISq * aSqPlusBSq + sinThetaIQu) + (2.0f * a * cosThetaI * sinThetaISq));
+    return 0.5f * (Rs + Rs * Rp);
+}
+static v3 conductorReflectance3(const float* eta, const float* k, float cosThetaI) {
+    return V(conductorReflectance(eta[0], k[0], cosThetaI), conductorReflectance(eta[1], k[1], cosThetaI), conductorReflectance(eta[2], k[2], cosThetaI));
+}
+static float dielectricReflectance(float eta, float cosThetaI, float* cosThetaT) {
+    if (cosThetaI < 0.0f) { eta = 1.0f / eta; cosThetaI = -cosThetaI; }
+    float sinThetaTSq = eta * eta * (1.0f - cosThetaI * cosThetaI);
+    if (sinThetaTSq > 1.0f) { *cosThetaT = 0.0f; return 1.0f; }
+    *cosThetaT = prt_sqrt(prt_fmax(1.0f - sinThetaTSq, 0.0f));
+    float Rs = (eta * cosThetaI - *cosThetaT) / (eta * cosThetaI + *cosThetaT);
+    float Rp = (eta * *cosThetaT - cosThetaI) / (eta * *cosThetaT + cosThetaI);
+    return (Rs * Rs + Rp * Rp) * 0.5f;
+}
+
+/* ---- kernels/bxdf/microfacet.cl:11-108 ---- */
+static float roughnessToAlpha(int dist, float roughness) {
+    roughness = prt_fmax(roughness, 1e-3f);
+    if (dist & PRT_DIST_PHONG) return 2.0f / (roughness * roughness) - 2.0f;
+    return roughness;
+}
+static float Microfacet_D(int dist, float alpha, v3 m) {
+    if (m.z <= 0.0f) return 0.0f;
+    if (dist & PRT_DIST_BECKMANN) {
+        float alphaSq = alpha * alpha, cosThetaSq = m.z * m.z;
+        float tanThetaSq = prt_fmax(1.0f - cosThetaSq, 0.0f) / cosThetaSq;
+        float cosThetaQu = cosThetaSq * cosThetaSq;
+        return INV_PI * prt_exp(-tanThetaSq / alphaSq) / (alphaSq * cosThetaQu);
+    } else if (dist & PRT_DIST_PHONG) {
+        return (alpha + 2.0f) * INV_TWO_PI * prt_pow(m.z, alpha);
+    } else if (dist & PRT_DIST_GGX) {
+        float alphaSq = alpha * alpha, cosThetaSq = m.z * m.z;
+        float tanThetaSq = prt_fmax(1.0f - cosThetaSq, 0.0f) / cosThetaSq;
+        float cosThetaQu = cosThetaSq * cosThetaSq;
+        return alphaSq * INV_PI / (cosThetaQu * prt_pow(alphaSq + tanThetaSq, 2.0f));
+    }
+    return 0.0f;
+}
+static float Microfacet_G1(int dist, float alpha, v3 v, v3 m) {
+    if (vdot(v, m) * v.z <= 0.0f) return 0.0f;
+    if (dist & PRT_DIST_BECKMANN) {
+        float cosThetaSq = v.z * v.z;
+        float tanTheta = prt_fabs(prt_sqrt(prt_fmax(1.0f - cosThetaSq, 0.0f)) / v.z);
+        float a = 1.0f / (alpha * tanTheta);
+        if (a < 1.6f) return (3.535f * a + 2.181f * a * a) / (1.0f + 2.276f * a + 2.577f * a * a);
+        return 1.0f;
+    } else if (dist & PRT_DIST_PHONG) {
+        float cosThetaSq = v.z * v.z;
+        float tanTheta = prt_fabs(prt_sqrt(prt_fmax(1.0f - cosThetaSq, 0.0f)) / v.z);
+        float a = prt_sqrt(0.5f * alpha + 1.0f) / tanTheta;
+        if (a < 1.6f) return (3.535f * a + 2.181f * a * a) / (1.0f + 2.276f * a + 2.577f * a * a);
+        return 1.0f;
+    } else if (dist & PRT_DIST_GGX) {
+        float alphaSq = alpha * alpha, cosThetaSq = v.z * v.z;
+        float tanThetaSq = prt_fmax(1.0f - cosThetaSq, 0.0f) / cosThetaSq;
+        return 2.0f / (1.0f + prt_sqrt(1.0f + alphaSq * tanThetaSq));
+    }
+    return 0.0f;
+}
+static float Microfacet_G(int dist, float alpha, v3 i, v3 o, v3 m) { return Microfacet_G1(dist, alpha, i, m) * Microfacet_G1(dist, alpha, o, m); }
+static float Microfacet_pdf(int dist, float alpha, v3 m) { return Microfacet_D(dist, alpha, m) * m.z; }
+static v3 Microfacet_sample(int dist, float alpha, float xi_x, float xi_y) {
+    float phi = xi_y * TWO_PI;
+    float cosTheta = 0.0f;
+    if (dist & PRT_DIST_BECKMANN) {
+        float tanThetaSq = -alpha * alpha * prt_log(1.0f - xi_x);
+        cosTheta = 1.0f / prt_sqrt(1.0f + tanThetaSq);
+    } else if (dist & PRT_DIST_PHONG) {
+        cosTheta = prt_pow(xi_x, 1.0f / (alpha + 2.0f));
+    } else if (dist & PRT_DIST_GGX) {
+        float tanThetaSq = alpha * alpha * xi_x / (1.0f - xi_x);
+        cosTheta = 1.0f / prt_sqrt(1.0f + tanThetaSq);
+    }
+    float r = prt_sqrt(prt_fmax(1.0f - cosTheta * cosTheta, 0.0f));
+    return V(prt_cos(phi) * r, prt_sin(phi) * r, cosTheta);
+}
+
+/* ---- kernels/bxdf/Materials/Lambert.cl:4-31 ---- */
+static int LambertBSDF(SurfaceScatterEvent* e, const prt_material* mat, Rng* rng) {
+    if (e->wi.z <= 0.0f) return 0;
+    float xi_x = next1D(rng), xi_y = next1D(rng);
+    e->wo = cosineHemisphere(xi_x, xi_y);
+    e->pdf = cosineHemispherePdf(e->wo);
+    e->weight = vload(mat->color);
+    e->sampledLobe = PRT_LOBE_DIFFUSE_R;
+    return 1;
+}
+static v3 LambertBSDF_eval(const SurfaceScatterEvent* e, const prt_material* mat) {
+    if (e->wi.z <= 0.0f || e->wo.z <= 0.0f) return vsplat(0.0f);
+    return vscale(vscale(vload(mat->color), INV_PI), e->wo.z);
+}
+/* Lambert.cl:26-31 falls off the end on the valid path; every LLVM build folds phi(0, undef) to 0 (Q7) */
+static float LambertBSDF_pdf(const SurfaceScatterEvent* e) { (void)e; return 0.0f; }
+
+/* ---- kernels/bxdf/Materials/Conductor.cl:4-29 ---- */
+static int ConductorBSDF(SurfaceScatterEvent* e, const prt_material* mat) {
+    v3 F = conductorReflectance3(mat->eta, mat->k, e->wi.z);
+    e->wo = V(-e->wi.x, -e->wi.y, e->wi.z);
+    e->pdf = 1.0f;
+    e->weight = vmul(vload(mat->color), F);
+    e->sampledLobe = PRT_LOBE_SPECULAR_R;
+    return 1;
+}
+static v3 ConductorBSDF_eval(const SurfaceScatterEvent* e, const prt_material* mat) {
+    v3 F = conductorReflectance3(mat->eta, mat->k, e->wi.z);
+    if (checkReflectionConstraint(e->wi, e->wo)) return vmul(vload(mat->color), F);
+    return vsplat(0.0f);
+}
+static float ConductorBSDF_pdf(const SurfaceScatterEvent* e) { return (float)checkReflectionConstraint(e->wi, e->wo); }
+
+/* ---- kernels/bxdf/Materials/RoughConductor.cl:4-62 ---- */
+static int RoughConductorBSDF(SurfaceScatterEvent* e, const prt_material* mat, Rng* rng) {
+    if (e->wi.z <= 0.0f) return 0;
+    float alpha = roughnessToAlpha(mat->dist, mat->roughness);
+    float xi_x = next1D(rng), xi_y = next1D(rng);
+    v3 m = Microfacet_sample(mat->dist, alpha, xi_x, xi_y);
+    float wiDotM = vdot(e->wi, m);
+    e->wo = vsub(vscale(m, 2.0f * wiDotM), e->wi);
+    if (wiDotM <= 0.0f || e->wo.z <= 0.0f) return 0;
+    float G = Microfacet_G(mat->dist, alpha, e->wi, e->wo, m);
+    float D = Microfacet_D(mat->dist, alpha, m);
+    float mPdf = Microfacet_pdf(mat->dist, alpha, m);
+    float pdf = mPdf * 0.25f / wiDotM;
+    float weight = wiDotM * G * D / (e->wi.z * mPdf);
+    v3 F = conductorReflectance3(mat->eta, mat->k, wiDotM);
+    e->pdf = pdf;
+    e->weight = vscale(vmul(vload(mat->color), F), weight);
+    e->sampledLobe = PRT_LOBE_GLOSSY_R;
+    return 1;
+}
+static v3 RoughConductorBSDF_eval(const SurfaceScatterEvent* e, const prt_material* mat) {
+    if (e->wi.z <= 0.0f || e->wo.z <= 0.0f) return vsplat(0.0f);
+    float alpha = roughnessToAlpha(mat->dist, mat->roughness);
+    v3 hr = vnormalize(vadd(e->wi, e->wo));
+    float cosThetaM = vdot(e->wi, hr);
+    v3 F = conductorReflectance3(mat->eta, mat->k, cosThetaM);
+    float G = Microfacet_G(mat->dist, alpha, e->wi, e->wo, hr);
+    float D = Microfacet_D(mat->dist, alpha, hr);
+    float fr = (G * D * 0.25f) / e->wi.z;
+    return vmul(vload(mat->color), vscale(F, fr));
+}
+static float RoughConductorBSDF_pdf(const SurfaceScatterEvent* e, const prt_material* mat) {
+    if (e->wi.z <= 0.0f || e->wo.z <= 0.0f) return 0.0f;
+    float sampleAlpha = roughnessToAlpha(mat->dist, mat->roughness);
+    v3 hr = vnormalize(vadd(e->wi, e->wo));
+    return Microfacet_pdf(mat->dist, sampleAlpha, hr) * 0.25f / vdot(e->wi, hr);
+}
+
+/* ---- kernels/bxdf/Materials/Dielectric.cl:4-87 ---- */
+static v3 absorb_weight(v3 weight, const prt_material* mat, const Ray* ray) {
+    /* Dielectric.cl:30-37 == RoughDielectric.cl:55-62 */
+    const int ABS1 = (mat->t & PRT_MAT_ABS_REFR) != 0, ABS2 = (mat->t & PRT_MAT_ABS_REFR2) != 0;
+    const v3 color = vload(mat->color);
+    if (ABS1 | ABS2) {
+        weight = vmul(weight, ABS2 ? color : vsplat(1.0f));
+        if (ray->backside) {
+            v3 c = ABS1 ? color : vsplat(1.0f);
+            v3 a = vscale(vscale(c, -ray->t), 10.0f);          /* -ray->t * c * 10.0f */
+            weight = vmul(weight, vexp(a));
+        } else {
+            weight = vmul(weight, vsplat(1.0f));
+        }
+    } else {
+        weight = vmul(weight, color);
+    }
+    return weight;
+}
+static int DielectricBSDF(const Ray* ray, SurfaceScatterEvent* e, const prt_material* mat, Rng* rng) {
+    const float eta = e->wi.z < 0.0f ? mat->eta[0] : 1.0f / mat->eta[0];
+    float cosThetaT = 0.0f;
+    float F = dielectricReflectance(eta, prt_fabs(e->wi.z), &cosThetaT);
+    if (next1D(rng) < F) {
+        e->wo = V(-e->wi.x, -e->wi.y, e->wi.z);
+        e->pdf = F;
+        e->sampledLobe = PRT_LOBE_SPECULAR_R;
+        e->weight = vsplat(F);
+    } else {
+        if (F == 1.0f) return 0;
+        e->wo = V(-e->wi.x * eta, -e->wi.y * eta, -prt_copysign(cosThetaT, e->wi.z));
+        e->pdf = 1.0f - F;
+        e->sampledLobe = PRT_LOBE_SPECULAR_T;
+        e->weight = vsplat(1.0f - F);
+    }
+    e->weight = absorb_weight(e->weight, mat, ray);
+    return 1;
+}
+static v3 DielectricBSDF_eval(const SurfaceScatterEvent* e, const prt_material* mat) {
+    const float eta = e->wi.z < 0.0f ? mat->eta[0] : 1.0f / mat->eta[0];
+    float cosThetaT = 0.0f;
+    float F = dielectricReflectance(eta, prt_fabs(e->wi.z), &cosThetaT);
+    if (e->wi.z * e->wo.z >= 0.0f) {
+        if (checkReflectionConstraint(e->wi, e->wo)) return vscale(vload(mat->color), F);
+        return vsplat(0.0f);
+    } else {
+        if (checkRefractionConstraint(e->wi, e->wo, eta, cosThetaT)) return vscale(vload(mat->color), 1.0f - F);
+        return vsplat(0.0f);
+    }
+}
+static float DielectricBSDF_pdf(const SurfaceScatterEvent* e, const prt_material* mat) {
+    const float eta = e->wi.z < 0.0f ? mat->eta[0] : 1.0f / mat->eta[0];
+    float cosThetaT = 0.0f;
+    float F = dielectricReflectance(eta, prt_fabs(e->wi.z), &cosThetaT);
+    if (e->wi.z * e->wo.z >= 0.0f) return checkReflectionConstraint(e->wi, e->wo) ? F : 0.0f;
+    return checkRefractionConstraint(e->wi, e->wo, eta, cosThetaT) ? 1.0f - F : 0.0f;
+}
+static float Dielectric_eta(const SurfaceScatterEvent* e, const prt_material* mat) {   /* Dielectric.cl:82-87 == RoughDielectric.cl:132-137 */
+    if (e->wi.z * e->wo.z >= 0.0f) return 1.0f;
+    return e->wi.z < 0.0f ? mat->eta[0] : 1.0f / mat->eta[0];
+}
+
+/* ---- kernels/bxdf/Materials/RoughDielectric.cl:4-137 ---- */
+static inline float sgnE(float t) { return t < 0.0f ? -1.0f : 1.0f; }              /* utils.cl:43 */
+static int RoughDielectricBSDF(const Ray* ray, SurfaceScatterEvent* e, const prt_material* mat, Rng* rng) {
+    const float wiDotN = e->wi.z;
+    const float eta = e->wi.z < 0.0f ? mat->eta[0] : 1.0f / mat->eta[0];
+    float sampleRoughness = (1.2f - 0.2f * prt_sqrt(prt_fabs(wiDotN))) * mat->roughness;
+    float alpha = roughnessToAlpha(mat->dist, mat->roughness);
+    float sampleAlpha = roughnessToAlpha(mat->dist, sampleRoughness);
+    float xi_x = next1D(rng), xi_y = next1D(rng);
+    v3 m = Microfacet_sample(mat->dist, sampleAlpha, xi_x, xi_y);
+    float pm = Microfacet_pdf(mat->dist, sampleAlpha, m);
+    if (pm < 1e-10f) return 0;
+    float wiDotM = vdot(e->wi, m);
+    float cosThetaT = 0.0f;
+    float F = dielectricReflectance(1.0f / mat->eta[0], wiDotM, &cosThetaT);
+    float etaM = wiDotM < 0.0f ? mat->eta[0] : 1.0f / mat->eta[0];
+    int reflect = next1D(rng) < F;
+    if (reflect) e->wo = vsub(vscale(m, 2.0f * wiDotM), e->wi);
+    else e->wo = vsub(vscale(m, etaM * wiDotM - sgnE(wiDotM) * cosThetaT), vscale(e->wi, etaM));
+    float woDotN = e->wo.z;
+    int reflected = wiDotN * woDotN > 0.0f;
+    if (reflected != reflect) return 0;
+    float woDotM = vdot(e->wo, m);
+    float G = Microfacet_G(mat->dist, alpha, e->wi, e->wo, m);
+    float D = Microfacet_D(mat->dist, alpha, m);
+    e->weight = vsplat(prt_fabs(wiDotM) * G * D / (prt_fabs(wiDotN) * pm));
+    if (reflect) {
+        e->pdf = F * pm * 0.25f / prt_fabs(wiDotM);
+        e->sampledLobe = PRT_LOBE_GLOSSY_R;
+    } else {
+        e->pdf = (1.0f - F) * pm * prt_fabs(woDotM) / prt_pow(eta * wiDotM + woDotM, 2.0f);
+        e->sampledLobe = PRT_LOBE_GLOSSY_T;
+    }
+    e->weight = absorb_weight(e->weight, mat, ray);
+    return 1;
+}
+static void rough_diel_half(const SurfaceScatterEvent* e, float eta, int reflect, v3* m) {
+    float wiDotN = e->wi.z;
+    if (reflect) *m = vscale(vnormalize(vadd(e->wi, e->wo)), sgnE(wiDotN));
+    else *m = vneg(vnormalize(vadd(vscale(e->wi, eta), e->wo)));
+}
+static v3 RoughDielectricBSDF_eval(const SurfaceScatterEvent* e, const prt_material* mat) {
+    float wiDotN = e->wi.z, woDotN = e->wo.z;
+    int reflect = wiDotN * woDotN >= 0.0f;
+    float alpha = roughnessToAlpha(mat->dist, mat->roughness);
+    const float eta = wiDotN < 0.0f ? mat->eta[0] : 1.0f / mat->eta[0];
+    v3 m;
+    rough_diel_half(e, eta, reflect, &m);
+    float wiDotM = vdot(e->wi, m), woDotM = vdot(e->wo, m);
+    float cosThetaT = 0.0f;
+    float F = dielectricReflectance(1.0f / mat->eta[0], wiDotM, &cosThetaT);
+    float G = Microfacet_G(mat->dist, alpha, e->wi, e->wo, m);
+    float D = Microfacet_D(mat->dist, alpha, m);
+    float fx;
+    if (reflect) fx = (F * G * D * 0.25f) / prt_fabs(wiDotN);
+    else fx = prt_fabs(wiDotM * woDotM) * (1.0f - F) * G * D / (prt_pow(eta * wiDotM + woDotM, 2.0f) * prt_fabs(wiDotN));
+    return vscale(vload(mat->color), fx);
+}
+static float RoughDielectricBSDF_pdf(const SurfaceScatterEvent* e, const prt_material* mat) {
+    float wiDotN = e->wi.z, woDotN = e->wo.z;
+    int reflect = wiDotN * woDotN >= 0.0f;
+    float sampleRoughness = (1.2f - 0.2f * prt_sqrt(prt_fabs(wiDotN))) * mat->roughness;
+    float sampleAlpha = roughnessToAlpha(mat->dist, sampleRoughness);
+    float eta = wiDotN < 0.0f ? mat->eta[0] : 1.0f / mat->eta[0];
+    v3 m;
+    rough_diel_half(e, eta, reflect, &m);
+    float wiDotM = vdot(e->wi, m), woDotM = vdot(e->wo, m);
+    float cosThetaT = 0.0f;
+    float F = dielectricReflectance(1.0f / mat->eta[0], wiDotM, &cosThetaT);
+    float pm = Microfacet_pdf(mat->dist, sampleAlpha, m);
+    if (reflect) return F * pm * 0.25f / prt_fabs(wiDotM);
+    return (1.0f - F) * pm * prt_fabs(woDotM) / prt_pow(eta * wiDotM + woDotM, 2.0f);
+}
+
+/* ---- kernels/bxdf/Materials/Coat.cl:4-112 (ior 1.3, thickness 1, sigmaA 0) ---- */
+#define COAT_IOR 1.3f
+static int CoatBSDF(SurfaceScatterEvent* e, const prt_material* mat, Rng* rng) {
+    if (e->wi.z <= 0.0f) return 0;
+    const float eta = 1.0f / COAT_IOR;
+    const float avgTransmittance = prt_exp(-2.0f * (1.0f * 0.0f));
+    float cosThetaTi;
+    float Fi = dielectricReflectance(eta, e->wi.z, &cosThetaTi);
+    float specularProbability = Fi / (Fi + avgTransmittance * (1.0f - Fi));
+    if (next1D(rng) < specularProbability) {
+        e->wo = V(-e->wi.x, -e->wi.y, e->wi.z);
+        e->pdf = specularProbability;
+        e->weight = vsplat(Fi / specularProbability);
+        e->sampledLobe = PRT_LOBE_SPECULAR_R;
+    } else {
+        v3 originalWi = e->wi;
+        e->wi = V(originalWi.x * eta, originalWi.y * eta, cosThetaTi);
+        if (!RoughConductorBSDF(e, mat, rng)) return 0;
+        e->wi = originalWi;
+        float cosThetaTo;
+        float Fo = dielectricReflectance(COAT_IOR, e->wo.z, &cosThetaTo);
+        if (Fo == 1.0f) return 0;
+        float cosThetaSubstrate = e->wo.z;
+        e->wo = V(e->wo.x * COAT_IOR, e->wo.y * COAT_IOR, cosThetaTo);
+        e->weight = vscale(e->weight, (1.0f - Fi) * (1.0f - Fo));
+        e->weight = vdivs(e->weight, 1.0f - specularProbability);
+        e->pdf *= 1.0f - specularProbability;
+        e->pdf *= eta * eta * cosThetaTo / cosThetaSubstrate;
+    }
+    return 1;
+}
+static v3 CoatBSDF_eval(const SurfaceScatterEvent* e, const prt_material* mat) {
+    if (e->wi.z <= 0.0f || e->wo.z <= 0.0f) return vsplat(0.0f);
+    const float eta = 1.0f / COAT_IOR;
+    float cosThetaTi;
+    float Fi = dielectricReflectance(eta, e->wi.z, &cosThetaTi);
+    if (checkReflectionConstraint(e->wi, e->wo)) return vsplat(Fi);
+    float cosThetaTo;
+    float Fo = dielectricReflectance(eta, e->wo.z, &cosThetaTo);
+    SurfaceScatterEvent nE = *e;
+    nE.wi = V(e->wi.x * eta, e->wi.y * eta, prt_copysign(cosThetaTi, e->wi.z));
+    nE.wo = V(e->wo.x * eta, e->wo.y * eta, prt_copysign(cosThetaTo, e->wo.z));
+    v3 substrateF = RoughConductorBSDF_eval(&nE, mat);
+    float laplacian = eta * eta * e->wo.z / cosThetaTo;
+    return vscale(substrateF, laplacian * (1.0f - Fi) * (1.0f - Fo));
+}
+static float CoatBSDF_pdf(const SurfaceScatterEvent* e, const prt_material* mat) {
+    if (e->wi.z <= 0.0f || e->wo.z <= 0.0f) return 0.0f;
+    const float eta = 1.0f / COAT_IOR;
+    const float avgTransmittance = prt_exp(-2.0f * (1.0f * 0.0f));
+    float cosThetaTi;
+    float Fi = dielectricReflectance(eta, e->wi.z, &cosThetaTi);
+    float specularProbability = Fi / (Fi + avgTransmittance * (1.0f - Fi));
+    if (checkReflectionConstraint(e->wi, e->wo)) return specularProbability;
+    float cosThetaTo;
+    dielectricReflectance(eta, e->wo.z, &cosThetaTo);
+    SurfaceScatterEvent nE = *e;
+    nE.wi = V(e->wi.x * eta, e->wi.y * eta, prt_copysign(cosThetaTi, e->wi.z));
+    nE.wo = V(e->wo.x * eta, e->wo.y * eta, prt_copysign(cosThetaTo, e->wo.z));
+    return RoughConductorBSDF_pdf(&nE, mat) * (1.0f - specularProbability) * eta * eta * prt_fabs(e->wo.z / cosThetaTo);
+}
+
+/* ---- kernels/bxdf/bxdf.cl:57-273 dispatch (first matching type bit in the reference's order) ---- */
+static int BSDF(const Scene* sc, SurfaceScatterEvent* e, const Ray* ray, const prt_material* mat, Rng* rng) {
+    const unsigned t = mat->t & sc->cfg->active_mats;   /* a branch exists only if its type is compiled in */
+    if (t & PRT_MAT_DIFF) return LambertBSDF(e, mat, rng);
+    else if (t & PRT_MAT_COND) return ConductorBSDF(e, mat);
+    else if (t & PRT_MAT_ROUGH_COND) return RoughConductorBSDF(e, mat, rng);
+    else if (t & PRT_MAT_DIEL) return DielectricBSDF(ray, e, mat, rng);
+    else if (t & PRT_MAT_ROUGH_DIEL) return RoughDielectricBSDF(ray, e, mat, rng);
+    else if (t & PRT_MAT_COAT) return CoatBSDF(e, mat, rng);
+    return 0;
+}
+static float nonadjoint_eta(const Scene* sc, const SurfaceScatterEvent* e, const prt_material* mat) {
+    /* bxdf.cl:121-140 / :204-223 : only compiled when DIEL or ROUGH_DIEL is active */
+    const unsigned t = mat->t & sc->cfg->active_mats;
+    float eta = 1.0f;
+    if (t & PRT_MAT_DIEL) eta = Dielectric_eta(e, mat);
+    else if (t & PRT_MAT_ROUGH_DIEL) eta = Dielectric_eta(e, mat);
+    return eta;
+}
+static int BSDF2(const Scene* sc, SurfaceScatterEvent* e, const Ray* ray, const prt_material* mat, Rng* rng) {
+    if (!BSDF(sc, e, ray, mat, rng)) return 0;
+    if (sc->cfg->active_mats & (PRT_MAT_DIEL | PRT_MAT_ROUGH_DIEL)) {
+        float eta = nonadjoint_eta(sc, e, mat);
+        e->weight = vscale(e->weight, prt_pow(eta, 2.0f));
+    }
+    return 1;
+}
+static v3 BSDF_eval2(const Scene* sc, const SurfaceScatterEvent* e, const prt_material* mat) {
+    const unsigned t = mat->t & sc->cfg->active_mats;
+    v3 f;
+    if (t & PRT_MAT_DIFF) f = LambertBSDF_eval(e, mat);
+    else if (t & PRT_MAT_COND) f = ConductorBSDF_eval(e, mat);
+    else if (t & PRT_MAT_ROUGH_COND) f = RoughConductorBSDF_eval(e, mat);
+    else if (t & PRT_MAT_DIEL) f = DielectricBSDF_eval(e, mat);
+    else if (t & PRT_MAT_ROUGH_DIEL) f = RoughDielectricBSDF_eval(e, mat);
+    else if (t & PRT_MAT_COAT) f = CoatBSDF_eval(e, mat);
+    else f = vsplat(0.0f);
+    if (sc->cfg->active_mats & (PRT_MAT_DIEL | PRT_MAT_ROUGH_DIEL)) {
+        float eta = nonadjoint_eta(sc, e, mat);
+        f = vscale(f, prt_pow(eta, 2.0f));
+    }
+    return f;
+}
+static float BSDF_pdf(const Scene* sc, const SurfaceScatterEvent* e, const prt_material* mat) {
+    const unsigned t = mat->t & sc->cfg->active_mats;
+    if (t & PRT_MAT_DIFF) return LambertBSDF_pdf(e);
+    else if (t & PRT_MAT_COND) return ConductorBSDF_pdf(e);
+    else if (t & PRT_MAT_ROUGH_COND) return RoughConductorBSDF_pdf(e, mat);
+    else if (t & PRT_MAT_DIEL) return DielectricBSDF_pdf(e, mat);
+    else if (t & PRT_MAT_ROUGH_DIEL) return RoughDielectricBSDF_pdf(e, mat);
+    else if (t & PRT_MAT_COAT) return CoatBSDF_pdf(e, mat);
+    return 0.0f;
+}
+
+/* ---- kernels/phasefunctions/{Isotropic.cl:6-24, HenyeyGreenstein.cl:4-48} ---- */
+static float hg(float g, float cosTheta) {
+    float term = 1.0f + g * g - 2.0f * g * cosTheta;
+    return INV_FOUR_PI * (1.0f - g * g) / (term * prt_sqrt(term));
+}
+static v3 phase_eval(const Scene* sc, v3 wi, v3 wo) {
+    if (sc->cfg->phase_function == PRT_PHASE_HG) return vsplat(hg(sc->cfg->phase_g, vdot(wi, wo)));
+    return vsplat(INV_FOUR_PI);
+}
+static float phase_pdf(const Scene* sc, v3 wi, v3 wo) {
+    if (sc->cfg->phase_function == PRT_PHASE_HG) return hg(sc->cfg->phase_g, vdot(wi, wo));
+    return INV_FOUR_PI;
+}
+static int phase_sample(const Scene* sc, v3 wi, PhaseSample* ps, Rng* rng) {
+    float xi_x = next1D(rng), xi_y = next1D(rng);
+    if (sc->cfg->phase_function == PRT_PHASE_HG) {
+        const float g = sc->cfg->phase_g;
+        if (g == 0.0f) {
+            ps->w = uniformSphere(xi_x, xi_y);
+            ps->pdf = INV_FOUR_PI;
+        } else {
+            float phi = xi_x * TWO_PI;
+            float cosTheta = (1.0f + g * g - prt_pow((1.0f - g * g) / (1.0f + g * (xi_y * 2.0f - 1.0f)), 2.0f)) / (2.0f * g);
+            float sinTheta = prt_sqrt(prt_fmax(1.0f - cosTheta * cosTheta, 0.0f));
+            TangentFrame tf = createTangentFrame(wi);
+            ps->w = toGlobal(&tf, V(prt_cos(phi) * sinTheta, prt_sin(phi) * sinTheta, cosTheta));
+            ps->pdf = hg(g, cosTheta);
+        }
+        ps->weight = vsplat(1.0f);
+        return 1;
+    }
+    ps->w = uniformSphere(xi_x, xi_y);
+    ps->weight = vsplat(1.0f);
+    ps->pdf = INV_FOUR_PI;
+    return 1;
+}
+
+/* ---- kernels/media/homogeneous.cl:11-51 ---- */
+static void HomogeneousMedium_sampleDistance(const Scene* sc, MediumSample* ms, const Ray* ray, Rng* rng) {
+    const prt_config* c = sc->cfg;
+    const v3 sigmaT = vsplat(c->fog_sigma_t), sigmaS = vsplat(c->fog_sigma_s);
+    const float maxT = ray->t;
+    if (c->fog_abs_only) {
+        ms->t = maxT;
+        ms->weight = vexp(vscale(sigmaT, -ms->t));
+        ms->pdf = 1.0f;
+        ms->exited = 1;
+    } else {
+        /* Q8: ((float*)&sigmaT)[(int)round(xi*3)] reads lane 0..3 of a float3; lane 3 is the padding
+         * lane, which the reference build fills with the same broadcast constant */
+        int lane = (int)prt_round(next1D(rng) * 3.0f);
+        float sigmaTc = (lane == 3) ? pto_medium_lane3(c) : c->fog_sigma_t;
+        float t = -prt_log(1.0f - next1D(rng)) / sigmaTc;
+        ms->t = prt_fmin(t, maxT);
+        ms->continuedT = t;
+        ms->exited = (t >= maxT);
+        v3 tau = vscale(sigmaT, ms->t);
+        v3 continuedTau = vscale(sigmaT, ms->continuedT);
+        ms->weight = vexp(vneg(tau));
+        ms->continuedWeight = vexp(vneg(continuedTau));
+        if (ms->exited) {
+            ms->pdf = avg3(vexp(vneg(tau)));
+        } else {
+            ms->pdf = avg3(vmul(sigmaT, vexp(vneg(tau))));
+            ms->weight = vmul(ms->weight, sigmaS);
+        }
+        ms->weight = vdivs(ms->weight, ms->pdf);
+        ms->continuedWeight = vdivs(vmul(sigmaS, ms->continuedWeight), avg3(vmul(sigmaT, vexp(vneg(continuedTau)))));
+    }
+    ms->p = vadd(ray->origin, vscale(ray->dir, ms->t));
+}
+
+/* ---- kernels/integrators/base.cl ---- */
+static inline float powerHeuristic(float pdf0, float pdf1) { return (pdf0 * pdf0) / (pdf0 * pdf0 + pdf1 * pdf1); }  /* :23-25 */
+
+static SurfaceScatterEvent makeLocalScatterEvent(const Ray* ray) {          /* :11-14 */
+    SurfaceScatterEvent e;
+    memset(&e, 0, sizeof(e));
+    e.frame = createTangentFrame(ray->normal);
+    e.wi = toLocal(&e.frame, vneg(ray->dir));
+    e.wo = vsplat(0.0f);
+    e.weight = vsplat(1.0f);
+    e.pdf = 1.0f;
+    return e;
+}
+
+static v3 bsdfSample(Scene* sc, SurfaceScatterEvent* e, Ray* ray, int has_medium, const prt_material* mat, Rng* rng, int* terminate) {  /* :31-77 */
+    if (!BSDF2(sc, e, ray, mat, rng)) { *terminate = 1; return vsplat(0.0f); }
+    v3 wo = toGlobal(&e->frame, e->wo);
+    ray->origin = ray->pos;
+    ray->dir = wo;
+    int mesh_id;
+    if (intersect_scene(sc, ray, &mesh_id)) {
+        const prt_mesh* light = &sc->meshes[mesh_id];
+        if (light->mat.t & PRT_MAT_LIGHT) {
+            v3 contribution = vscale(vmul(vload(light->mat.color), e->weight),
+                                     powerHeuristic(e->pdf, directPdf(sc, light, ray->dir, ray->pos)));
+            if (has_medium) contribution = vmul(contribution, vexp(vscale(vsplat(sc->cfg->fog_sigma_t), -1.0f * ray->t)));
+            return contribution;
+        }
+    }
+    return vsplat(0.0f);
+}
+
+static v3 lightSample(Scene* sc, SurfaceScatterEvent* e, const Ray* ray, int has_medium, const prt_material* mat, Rng* rng) {  /* :79-134 */
+    const prt_mesh* light = &sc->meshes[sc->cfg->light_indices[0]];
+    LightSample rec;
+    if (!sampleDirect(sc, light, ray->pos, &rec, rng)) return vsplat(0.0f);
+    e->wo = toLocal(&e->frame, rec.d);
+    v3 fr = BSDF_eval2(sc, e, mat);
+    if (vdot(fr, fr) == 0.0) return vsplat(0.0f);
+    Ray shadowRay;
+    memset(&shadowRay, 0, sizeof(shadowRay));
+    shadowRay.origin = ray->pos;
+    shadowRay.dir = rec.d;
+    shadowRay.t = rec.dist;
+    if (shadow(sc, &shadowRay)) {
+        v3 contribution = vmul(vload(light->mat.color), fr);
+        if (has_medium) contribution = vmul(contribution, vexp(vscale(vsplat(sc->cfg->fog_sigma_t), -1.0f * shadowRay.t)));
+        contribution = vscale(contribution, powerHeuristic(rec.pdf, BSDF_pdf(sc, e, mat)));
+        return vdivs(contribution, rec.pdf);
+    }
+    return vsplat(0.0f);
+}
+
+static int handleSurface(Scene* sc, SurfaceScatterEvent* e, Ray* ray, int has_medium, prt_material* mat, prt_path_state* st, v3* emission, Rng* rng) {  /* :138-192 */
+    int terminate = 0;
+    if ((sc->cfg->active_mats & PRT_MAT_LIGHT) && (mat->lobes & ~(PRT_LOBE_SPECULAR | PRT_LOBE_FORWARD))) {
+        v3 a = bsdfSample(sc, e, ray, has_medium, mat, rng, &terminate);       /* Q3: left operand first */
+        v3 b = lightSample(sc, e, ray, has_medium, mat, rng);
+        *emission = vadd(*emission, vmul(vadd(a, b), vload(st->mask)));
+    } else {
+        if (!BSDF2(sc, e, ray, mat, rng)) return 1;
+        ray->origin = ray->pos;
+        ray->dir = toGlobal(&e->frame, e->wo);
+    }
+    st->was_specular = (e->sampledLobe & PRT_LOBE_SPECULAR) != 0;
+    st->mask[0] *= e->weight.x; st->mask[1] *= e->weight.y; st->mask[2] *= e->weight.z;
+    st->diff += (e->sampledLobe & (PRT_LOBE_DIFFUSE_R | PRT_LOBE_GLOSSY_R)) != 0;
+    st->spec += (e->sampledLobe & PRT_LOBE_SPECULAR_R) != 0;
+    st->trans += (e->sampledLobe & PRT_LOBE_TRANSMISSIVE) != 0;
+    return terminate;
+}
+
+static v3 volumeLightSample(Scene* sc, const MediumSample* ms, const Ray* ray, Rng* rng) {      /* :194-230 */
+    const prt_mesh* light = &sc->meshes[sc->cfg->light_indices[0]];
+    LightSample rec;
+    if (!sampleDirect(sc, light, ray->pos, &rec, rng)) return vsplat(0.0f);     /* ray->pos, not ms->p (Q4) */
+    v3 f = phase_eval(sc, ray->dir, rec.d);
+    if (vdot(f, f) == 0.0f) return vsplat(0.0f);
+    Ray sRay;
+    memset(&sRay, 0, sizeof(sRay));
+    sRay.origin = ms->p;
+    sRay.dir = rec.d;
+    sRay.t = rec.dist;
+    if (shadow(sc, &sRay)) {
+        v3 tr = vexp(vscale(vsplat(sc->cfg->fog_sigma_t), -1.0f * sRay.t));
+        v3 contribution = vscale(vmul(vmul(tr, vload(light->mat.color)), f), powerHeuristic(rec.pdf, phase_pdf(sc, ray->dir, rec.d)));
+        return vdivs(contribution, rec.pdf);
+    }
+    return vsplat(0.0f);
+}
+static v3 volumePhaseSample(Scene* sc, const MediumSample* ms, PhaseSample* ps, const Ray* ray, Rng* rng) {   /* :232-260 */
+    if (!phase_sample(sc, ray->dir, ps, rng)) return vsplat(0.0f);
+    Ray sRay;
+    memset(&sRay, 0, sizeof(sRay));
+    sRay.origin = ms->p;
+    sRay.dir = ps->w;
+    int mesh_id;
+    if (intersect_scene(sc, &sRay, &mesh_id)) {
+        const prt_mesh* light = &sc->meshes[mesh_id];
+        if (light->mat.t & PRT_MAT_LIGHT) {
+            v3 tr = vexp(vscale(vsplat(sc->cfg->fog_sigma_t), -1.0f * sRay.t));
+            return vscale(vmul(vmul(tr, vload(light->mat.color)), ps->weight),
+                          powerHeuristic(ps->pdf, directPdf(sc, light, sRay.dir, ms->p)));
+        }
+    }
+    return vsplat(0.0f);
+}
+
+/* ---- env map: kernels/utils.cl:46 + read_imagef with samplerA (kernels/main.cl:25) ---- */
+static void env_texel(const Scene* sc, int i, int j, float* rgb) {
+    if (i < 0 || j < 0 || i >= sc->env_w || j >= sc->env_h) { rgb[0] = rgb[1] = rgb[2] = 0.0f; return; }
+    const float* p = sc->env + ((size_t)j * sc->env_w + i) * 3;
+    rgb[0] = p[0]; rgb[1] = p[1]; rgb[2] = p[2];
+}
+static v3 env_lookup(const Scene* sc, v3 dir) {
+    float cx = (prt_atan2(dir.z, dir.x) * INV_TWO_PI) + 0.5f;
+    float cy = prt_acos(dir.y) * INV_PI;
+    float u = cx * (float)sc->env_w, v = cy * (float)sc->env_h;
+    float fu = prt_floor(u - 0.5f), fv = prt_floor(v - 0.5f);
+    float a = (u - 0.5f) - fu, b = (v - 0.5f) - fv;
+    int i0 = (int)fu, j0 = (int)fv;
+    float t00[3], t10[3], t01[3], t11[3], o[3];
+    env_texel(sc, i0, j0, t00); env_texel(sc, i0 + 1, j0, t10); env_texel(sc, i0, j0 + 1, t01); env_texel(sc, i0 + 1, j0 + 1, t11);
+    for (int k = 0; k < 3; ++k)
+        o[k] = (1.f - a) * (1.f - b) * t00[k] + a * (1.f - b) * t10[k] + (1.f - a) * b * t01[k] + a * b * t11[k];
+    return V(o[0], o[1], o[2]);
+}
+
+/* ---- kernels/integrators/pathtracing.cl:4-120 ---- */
+static void radiance(Scene* sc, Ray* ray, prt_path_state* st, Rng* rng, float out[4]) {
+    const prt_config* c = sc->cfg;
+    const int has_medium = c->has_global_medium != 0;
+    float alpha = 1.0f;
+    v3 emission = vsplat(0.0f);
+    int mesh_id;
+    int didHit = intersect_scene(sc, ray, &mesh_id);
+    prt_material mat = (mesh_id + 1) ? sc->meshes[mesh_id].mat : *sc->obj_mat;
+    int scattered = 0;
+    if (has_medium) {
+        MediumSample ms;
+        memset(&ms, 0, sizeof(ms));
+        ms.continuedWeight = vload(st->mask);
+        HomogeneousMedium_sampleDistance(sc, &ms, ray, rng);
+        st->mask[0] *= ms.weight.x; st->mask[1] *= ms.weight.y; st->mask[2] *= ms.weight.z;
+        if (!ms.exited && (int)st->scatters < c->max_scattering_events) {
+            scattered = 1;
+            ++st->scatters;
+            PhaseSample ps;
+            memset(&ps, 0, sizeof(ps));
+            st->was_specular = 0;      /* !(enableVolumeLightSampling && (lowOrderScattering || scatters > 1)) == false */
+            {
+                v3 a = volumeLightSample(sc, &ms, ray, rng);
+                v3 b = volumePhaseSample(sc, &ms, &ps, ray, rng);
+                emission = vadd(emission, vmul(vadd(a, b), vload(st->mask)));
+            }
+            ray->origin = ms.p;
+            ray->dir = ps.w;
+            st->mask[0] *= ps.weight.x; st->mask[1] *= ps.weight.y; st->mask[2] *= ps.weight.z;
+        }
+    }
+    if (!scattered) {
+        if (!didHit) {
+            st->reset = 1;
+            if (c->alpha_testing) { out[0] = out[1] = out[2] = out[3] = 0.0f; return; }
+            v3 e = env_lookup(sc, ray->dir);
+            out[0] = st->mask[0] * e.x; out[1] = st->mask[1] * e.y; out[2] = st->mask[2] * e.z; out[3] = 1.0f;
+            return;
+        }
+        if ((c->active_mats & PRT_MAT_LIGHT) && (mat.t & PRT_MAT_LIGHT)) {
+            if (st->was_specular) emission = vadd(emission, vmul(vload(mat.color), vload(st->mask)));
+            st->reset = 1;
+            goto done;
+        }
+        SurfaceScatterEvent ev = makeLocalScatterEvent(ray);
+        if (handleSurface(sc, &ev, ray, has_medium, &mat, st, &emission, rng)) { st->reset = 1; goto done; }
+        st->scatters = 0;
+        ++st->total;
+    }
+    {
+        const float roulettePdf = fmax3(vload(st->mask));
+        if (st->total > 2 && roulettePdf < 0.1f) {
+            if (next1D(rng) < roulettePdf) {
+                st->mask[0] /= roulettePdf; st->mask[1] /= roulettePdf; st->mask[2] /= roulettePdf;
+            } else {
+                st->reset = 1;
+                goto done;
+            }
+        }
+    }
+    if (st->total >= (uint32_t)c->max_bounces || (int)st->diff >= c->max_diff_bounces ||
+        (int)st->spec >= c->max_spec_bounces || (int)st->trans >= c->max_trans_bounces)
+        st->reset = 1;
+done:
+    out[0] = emission.x; out[1] = emission.y; out[2] = emission.z; out[3] = alpha;
+}
+
+/* ---- kernels/main.cl:66-163 render_kernel, one work-item ---- */
+static void render_pixel(Scene* sc, const prt_camera* cam, int width, int height, int gx, int gy,
+                         uint32_t framenumber, int32_t random0, int32_t random1, prt_path_state* st, float* pixel_rgba) {
+    Rng rng;
+    rng.s0 = (uint32_t)gx * framenumber % 1000u + ((uint32_t)random0 * 100u);     /* main.cl:108-109 (Q14) */
+    rng.s1 = (uint32_t)gy * framenumber % 1000u + ((uint32_t)random1 * 100u);
+    Ray ray;                                                    /* tempToRay, main.cl:27 */
+    memset(&ray, 0, sizeof(ray));
+    ray.origin = vload(st->origin);
+    ray.dir = vload(st->dir);
+    ray.t = st->dist;
+    ray.time = st->time;
+    if (st->reset || st->samples == 0) {
+        ++st->samples;
+        st->total = 0; st->diff = 0; st->spec = 0; st->trans = 0; st->scatters = 0;
+        st->was_specular = 1;
+        st->reset = 0;
+        st->mask[0] = st->mask[1] = st->mask[2] = 1.0f;
+        ray = createCamRay(gx, gy, width, height, cam, &rng);
+    }
+    float r[4];
+    radiance(sc, &ray, st, &rng, r);
+    st->acc[0] += r[0]; st->acc[1] += r[1]; st->acc[2] += r[2]; st->acc[3] += r[3];
+    st->origin[0] = ray.origin.x; st->origin[1] = ray.origin.y; st->origin[2] = ray.origin.z;   /* rayToTemp, main.cl:28 */
+    st->dir[0] = ray.dir.x; st->dir[1] = ray.dir.y; st->dir[2] = ray.dir.z;
+    st->time = ray.t;           /* positional initialiser { origin, dir, ray.t, ray.time } into { origin, dir, time, dist } */
+    st->dist = ray.time;
+    const float ns = (float)st->samples;
+    pixel_rgba[0] = st->acc[0] / ns; pixel_rgba[1] = st->acc[1] / ns; pixel_rgba[2] = st->acc[2] / ns; pixel_rgba[3] = st->acc[3] / ns;
+}
+
+float pto_medium_lane3(const prt_config* c) { return c->fog_sigma_t; }
+
+/* ---- driver ------------------------------------------------------------------------------- */
+typedef struct {
+    const pto_job* job;
+    Scene scene;
+    size_t lo, hi;
+} Worker;
+
+static void* worker_main(void* arg) {
+    Worker* w = (Worker*)arg;
+    const pto_job* j = w->job;
+    for (size_t id = w->lo; id < w->hi; ++id) {
+        const int lx = (int)(id % (size_t)j->width), ly = (int)(id / (size_t)j->width);
+        const int gx = lx, gy = ly + j->row0;
+        prt_path_state* st = &j->state[id];
+        float* px = j->out_rgba + 4 * id;
+        for (uint32_t f = 0; f < j->n_frames; ++f) {
+            if (j->spp_limit && st->reset && st->samples >= j->spp_limit) break;
+            render_pixel(&w->scene, j->camera, j->width, j->full_height, gx, gy, j->first_frame + f,
+                         j->seed_pairs[2 * f], j->seed_pairs[2 * f + 1], st, px);
+        }
+    }
+    return NULL;
+}
+
+int pto_render(const pto_job* j, pto_diag* diag) {
+    if (!j || !j->cfg || !j->scene || !j->camera || !j->state || !j->out_rgba) return -1;
+    const prt_scene_desc* d = j->scene;
+    const uint32_t n_meshes = d->object_count[7];
+    if (d->object_count[1] || d->object_count[2]) return -5;         /* SDF / box: out of scope */
+    prt_mesh* guarded = (prt_mesh*)calloc((size_t)n_meshes + 1, sizeof(prt_mesh));   /* [0] = zero guard (Q6) */
+    if (!guarded) return -2;
+    if (n_meshes) memcpy(guarded + 1, d->meshes, (size_t)n_meshes * sizeof(prt_mesh));
+    static const prt_bvh_node empty_root = { {0, 0, 0, 0, 0, 0}, 0, 0, 1, {0, 0, 0} };
+    static const float black[3] = {0.f, 0.f, 0.f};
+    static const prt_material zero_mat;
+    Scene base;
+    memset(&base, 0, sizeof(base));
+    base.cfg = j->cfg;
+    base.meshes = guarded + 1;
+    base.counts = d->object_count;
+    base.indices = d->primitive_indices;
+    base.vertices = d->vertices;
+    base.normals = d->normals;
+    base.obj_mat = d->obj_material ? d->obj_material : &zero_mat;
+    base.nodes = (d->bvh_nodes && d->bvh_node_count) ? d->bvh_nodes : &empty_root;
+    base.env = j->env_rgb ? j->env_rgb : black;
+    base.env_w = j->env_rgb ? j->env_w : 1;
+    base.env_h = j->env_rgb ? j->env_h : 1;
+    base.nTransMask = (int)(j->cfg->active_mats & (PRT_MAT_DIEL | PRT_MAT_ROUGH_DIEL));
+
+    int nt = j->n_threads < 1 ? 1 : j->n_threads;
+    if (nt > 256) nt = 256;
+    const size_t npix = (size_t)j->width * (size_t)j->rows;
+    Worker* ws = (Worker*)calloc((size_t)nt, sizeof(Worker));
+    pthread_t* th = (pthread_t*)calloc((size_t)nt, sizeof(pthread_t));
+    /* interleaved blocks of 64 pixels would balance better; contiguous chunks keep it simple */
+    size_t chunk = (npix + (size_t)nt - 1) / (size_t)nt;
+    int started = 0;
+    for (int t = 0; t < nt; ++t) {
+        ws[t].job = j;
+        ws[t].scene = base;
+        ws[t].lo = (size_t)t * chunk;
+        ws[t].hi = ws[t].lo + chunk < npix ? ws[t].lo + chunk : npix;
+        if (ws[t].lo >= ws[t].hi) break;
+        if (nt == 1) worker_main(&ws[t]);
+        else pthread_create(&th[t], NULL, worker_main, &ws[t]);
+        ++started;
+    }
+    if (nt > 1) for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
+    if (diag) {
+        diag->max_stack = 0; diag->max_shadow_stack = 0;
+        for (int t = 0; t < started; ++t) {
+            if (ws[t].scene.max_stack > diag->max_stack) diag->max_stack = ws[t].scene.max_stack;
+            if (ws[t].scene.max_shadow_stack > diag->max_shadow_stack) diag->max_shadow_stack = ws[t].scene.max_shadow_stack;
+        }
+    }
+    free(ws); free(th); free(guarded);
+    return 0;
+}

@@ -80,7 +80,7 @@ def build_support(tmp):
     objs = []
     for src in ("clrt_shim.cpp", "ref_harness.cpp"):
         o = os.path.join(tmp, src + ".o")
-        run([CLANGXX, "-std=c++17", "-O2", "-ffp-contract=off", MARCH, "-fPIC", "-I%s/include" % ROOT,
+        run([CLANGXX, "-std=c++17", "-O2", "-ffp-contract=off", "-Wall", "-Werror", MARCH, "-fPIC", "-I%s/include" % ROOT,
              "-c", os.path.join(HERE, src), "-o", o])
         objs.append(o)
     return objs

@@ -42,9 +42,9 @@ static inline float4 texel(const ShimImage* im, int i, int j) {
     // CLK_ADDRESS_CLAMP: out-of-range coordinates return the border colour; for an image
     // without an alpha channel (the reference shares a GL_RGB32F texture,
     // include/GL/cl_gl_interop.h:71-86) that is (0,0,0,1).
-    if (i < 0 || j < 0 || i >= im->width || j >= im->height) return (float4)(0.f, 0.f, 0.f, 1.f);
+    if (i < 0 || j < 0 || i >= im->width || j >= im->height) return float4{0.f, 0.f, 0.f, 1.f};
     const float* p = im->data + ((size_t)j * im->width + i) * im->channels;
-    return (float4)(p[0], p[1], p[2], im->channels > 3 ? p[3] : 1.f);
+    return float4{p[0], p[1], p[2], im->channels > 3 ? p[3] : 1.f};
 }
 float4 shim_read_imagef(const ShimImage* im, void* sampler, float2 c)
     __asm__("_Z11read_imagef14ocl_image2d_ro11ocl_samplerDv2_f");
@@ -91,29 +91,29 @@ float shim_fract1(float x, float* ip) __asm__("_Z5fractfPU9CLprivatef");
 float shim_fract1(float x, float* ip) { *ip = prt_floor(x); return prt_fract(x); }
 
 // ---- float3 forms --------------------------------------------------------------------------
-#define V3(fn) (float3)(fn(v.x), fn(v.y), fn(v.z))
+#define V3(fn) float3{fn(v.x), fn(v.y), fn(v.z)}
 float3 exp(float3 v) { return V3(prt_exp); }
 float3 native_exp(float3 v) { return V3(prt_exp); }
 float3 native_recip(float3 v) { return V3(prt_recip); }
-float3 fmin(float3 a, float3 b) { return (float3)(prt_fmin(a.x, b.x), prt_fmin(a.y, b.y), prt_fmin(a.z, b.z)); }
-float3 fmax(float3 a, float3 b) { return (float3)(prt_fmax(a.x, b.x), prt_fmax(a.y, b.y), prt_fmax(a.z, b.z)); }
+float3 fmin(float3 a, float3 b) { return float3{prt_fmin(a.x, b.x), prt_fmin(a.y, b.y), prt_fmin(a.z, b.z)}; }
+float3 fmax(float3 a, float3 b) { return float3{prt_fmax(a.x, b.x), prt_fmax(a.y, b.y), prt_fmax(a.z, b.z)}; }
 float3 shim_fract3(float3 v, float3* ip) __asm__("_Z5fractDv3_fPU9CLprivateS_");
 float3 shim_fract3(float3 v, float3* ip) {
-    *ip = (float3)(prt_floor(v.x), prt_floor(v.y), prt_floor(v.z));
+    *ip = float3{prt_floor(v.x), prt_floor(v.y), prt_floor(v.z)};
     return V3(prt_fract);
 }
 float dot(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 float dot(float2 a, float2 b) { return a.x * b.x + a.y * b.y; }
 float3 cross(float3 a, float3 b) {
-    return (float3)(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+    return float3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
 float length(float3 v) { return prt_sqrt(v.x * v.x + v.y * v.y + v.z * v.z); }
 float fast_length(float3 v) { return prt_sqrt(v.x * v.x + v.y * v.y + v.z * v.z); }
 float3 normalize(float3 v) {
     float inv = 1.0f / prt_sqrt(v.x * v.x + v.y * v.y + v.z * v.z);
-    return (float3)(v.x * inv, v.y * inv, v.z * inv);
+    return float3{v.x * inv, v.y * inv, v.z * inv};
 }
 float3 fast_normalize(float3 v) {
     float inv = 1.0f / prt_sqrt(v.x * v.x + v.y * v.y + v.z * v.z);
-    return (float3)(v.x * inv, v.y * inv, v.z * inv);
+    return float3{v.x * inv, v.y * inv, v.z * inv};
 }
