@@ -899,7 +899,7 @@ static void HomogeneousMedium_sampleDistance(const Scene* sc, MediumSample* ms, 
         ms->exited = 1;
     } else {
         /* Q8: ((float*)&sigmaT)[(int)round(xi*3)] reads lane 0..3 of a float3; lane 3 is the padding
-         * lane, which the reference build fills with the same broadcast constant */
+         * lane, 0.0f in the reference build (see pto_medium_lane3) */
         int lane = (int)prt_round(next1D(rng) * 3.0f);
         float sigmaTc = (lane == 3) ? pto_medium_lane3(c) : c->fog_sigma_t;
         float t = -prt_log(1.0f - next1D(rng)) / sigmaTc;
@@ -1149,7 +1149,10 @@ static void render_pixel(Scene* sc, const prt_camera* cam, int width, int height
     pixel_rgba[0] = st->acc[0] / ns; pixel_rgba[1] = st->acc[1] / ns; pixel_rgba[2] = st->acc[2] / ns; pixel_rgba[3] = st->acc[3] / ns;
 }
 
-float pto_medium_lane3(const prt_config* c) { return c->fog_sigma_t; }
+/* Q8: the padding lane of the `const Medium` float3 members.  The reference build (clang, x86-64)
+ * materialises the struct as a constant whose padding lanes are 0.0f, so a draw that selects
+ * lane 3 (probability 1/6) samples with sigma_t = 0: t = +inf, the segment leaves the medium. */
+float pto_medium_lane3(const prt_config* c) { (void)c; return 0.0f; }
 
 /* ---- driver ------------------------------------------------------------------------------- */
 typedef struct {

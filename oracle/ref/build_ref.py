@@ -67,6 +67,16 @@ def make_farm(tmp):
     os.makedirs(os.path.join(tmp, "run"), exist_ok=True)
 
 
+def set_phase(tmp, phase):
+    """The reference selects the phase function by editing the '#FILE:phasefunctions/Isotropic.cl'
+    line of kernels/media.cl:61.  Same effect without touching text: point the
+    farm's Isotropic.cl link at the requested file."""
+    link = os.path.join(tmp, "kernels", "phasefunctions", "Isotropic.cl")
+    target = {"": "Isotropic.cl", "isotropic": "Isotropic.cl", "hg": "HenyeyGreenstein.cl"}[phase]
+    os.remove(link)
+    os.symlink(os.path.join(REF, "kernels", "phasefunctions", target), link)
+
+
 def build_host():
     os.makedirs(OUT, exist_ok=True)
     exe = os.path.join(OUT, "ref_host")
@@ -91,7 +101,7 @@ def build_variant(name, scene, width, height, alpha, shadow_stack, phase, blob_d
     blob = os.path.join(blob_dir, name + ".sceneblob")
     run([exe, os.path.abspath(scene), str(width), str(height), "1" if alpha else "0", cl, blob],
         cwd=os.path.join(tmp, "run"))
-    if shadow_stack or phase:
+    if shadow_stack:
         text = open(cl).read()
         if shadow_stack:
             needle = "#define STACK_SIZE 8\n"
@@ -116,7 +126,7 @@ def main():
     ap.add_argument("--height", type=int, default=64)
     ap.add_argument("--alpha", action="store_true")
     ap.add_argument("--shadow-stack", type=int, default=64)
-    ap.add_argument("--phase", default="", help="(reserved) phase-function variant")
+    ap.add_argument("--phase", default="", choices=["", "isotropic", "hg"], help="phase function of the global medium")
     ap.add_argument("--blob-dir", default=os.path.join(ROOT, "tests", "golden"))
     a = ap.parse_args()
     if not os.path.isdir(REF):
@@ -127,6 +137,7 @@ def main():
     try:
         make_farm(tmp)
         support = build_support(tmp)
+        set_phase(tmp, a.phase)
         for v in a.variant:
             name, scene = v.split("=", 1)
             so = build_variant(name, scene, a.width, a.height, a.alpha, a.shadow_stack, a.phase,
