@@ -16,23 +16,17 @@
  *         oracle under oracle/ (oracle/pt_oracle.c and the OpenCL runtime shim that lets the
  *         reference's own kernel text run on the host).
  *
- * Accuracy (tests/test_detmath.py, against float64 libm): sin/cos/tan <= 2 ulp on |x| <= 1e4,
- * exp/log <= 2 ulp, acos/atan2 <= 3 ulp, pow(x,2) exact, general pow <= ~(4+|y ln x|) ulp.
+ * Accuracy (tests/test_detmath.py, against float64 libm): sin/cos <= 2 ulp on |x| <= 1e4, tan <= 4 ulp,
+ * exp/log <= 2 ulp, acos/atan2 <= 3 ulp, pow(x,2) exact, general pow <= ~(4+4|y ln x|) ulp.
  * All inside the OpenCL 1.2 full-profile bounds except general pow with huge exponents.
  */
 #ifndef PRT_DETMATH_H
 #define PRT_DETMATH_H
 
-#if defined(__HIPCC__)
-#define PRT_HD __host__ __device__ __forceinline__
+#if defined(__HIP__)          /* clang in HIP mode: usable from host and device code */
+#define PRT_HD __attribute__((host)) __attribute__((device)) static inline __attribute__((always_inline))
 #else
 #define PRT_HD static inline
-#endif
-
-#ifdef __cplusplus
-#define PRT_DM_STATIC static
-#else
-#define PRT_DM_STATIC
 #endif
 
 /* ---- bit casts ------------------------------------------------------------------------- */

@@ -1,0 +1,211 @@
+"""photorealistic-rendering-using-opencl_amd -- MI355X-native drop-in for the radiance loop of
+Mourtz/Photorealistic-Rendering-using-OpenCL (kernels/main.cl render_kernel).
+
+The product is `libprt.so` (hand-written HIP for gfx950 behind the C ABI of include/prt.h, plus the
+C++ host model that keeps the reference's host_scene / Camera / BVH API).  This Python module is
+plumbing only: it mirrors the host sequence of the reference's src/main.cpp
+(load scene -> build BVH -> upload -> set camera -> render frames -> read the image) on top of the
+C ABI so tests, bench.py and torch.distributed launches can drive it.  Nothing here computes
+pixels and nothing falls back to a CPU path: without libprt.so or without a HIP device the calls
+raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _capi
+from ._capi import Camera, Config, SceneDesc, Stats, load_library, PATH_STATE_DTYPE
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+SCENES_DIR = os.path.join(REPO, "scenes")
+MODELS_DIR = os.path.join(SCENES_DIR, "models")
+
+__all__ = ["HostScene", "Renderer", "default_camera", "orbit_camera", "seed_pairs", "make_sky", "PrtError",
+           "Camera", "Config", "SceneDesc", "Stats", "PATH_STATE_DTYPE", "SCENES_DIR", "MODELS_DIR", "build"]
+
+
+class PrtError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """compile libprt.so in-tree (hipcc --offload-arch=gfx950)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_prt_build", os.path.join(HERE, "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.build(verbose=verbose)
+
+
+class HostScene:
+    """host_scene + ModelLoader + BVH of the reference's main() (src/main.cpp:375-415), through
+    csrc/host/host_capi.h.  Holds the host buffers the C ABI consumes."""
+
+    def __init__(self, scene_json, models_dir=None, text=False):
+        self.lib = load_library()
+        err = C.create_string_buffer(512)
+        md = (models_dir or MODELS_DIR).encode()
+        if text:
+            self.handle = self.lib.prth_scene_load_text(scene_json.encode(), md, err, 512)
+        else:
+            path = scene_json if os.path.exists(scene_json) else os.path.join(SCENES_DIR, scene_json)
+            self.handle = self.lib.prth_scene_load(path.encode(), md, err, 512)
+        if not self.handle:
+            raise PrtError("scene load failed: %s" % err.value.decode())
+        self.desc = SceneDesc()
+        self.lib.prth_scene_get_desc(self.handle, C.byref(self.desc))
+
+    def config(self, alpha_testing=False):
+        cfg = Config()
+        self.lib.prth_scene_get_config(self.handle, 1 if alpha_testing else 0, C.byref(cfg))
+        return cfg
+
+    @property
+    def bvh_depth(self):
+        return self.lib.prth_scene_bvh_depth(self.handle)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.prth_scene_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def default_camera(width, height, fovx=45.0):
+    """initCamera() + buildRenderCamera() of the reference (src/main.cpp:312-319)"""
+    cam = Camera()
+    rc = load_library().prth_default_camera(width, height, C.c_float(fovx), C.byref(cam))
+    if rc:
+        raise PrtError("prth_default_camera: %d" % rc)
+    return cam
+
+
+def orbit_camera(width, height, fovx=45.0, d_yaw=0.0, d_pitch=0.0, d_radius=0.0, d_aperture=0.0, d_focal=0.0):
+    cam = Camera()
+    rc = load_library().prth_orbit_camera(width, height, C.c_float(fovx), C.c_float(d_yaw), C.c_float(d_pitch),
+                                          C.c_float(d_radius), C.c_float(d_aperture), C.c_float(d_focal), C.byref(cam))
+    if rc:
+        raise PrtError("prth_orbit_camera: %d" % rc)
+    return cam
+
+
+def seed_pairs(n_frames, first_frame=1):
+    """(random0, random1) per frame: the un-seeded glibc rand() stream of the reference host,
+    two values consumed by initCLKernel first (src/main.cpp:226-227,301-302)."""
+    out = np.zeros(2 * n_frames, dtype=np.int32)
+    rc = load_library().prth_seed_pairs(first_frame, n_frames, out.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise PrtError("prth_seed_pairs: %d" % rc)
+    return out
+
+
+def make_sky(width=1024, height=512):
+    """deterministic procedural RGB32F environment map (stand-in for the -hdr file no one ships)"""
+    out = np.zeros((height, width, 3), dtype=np.float32)
+    rc = load_library().prth_make_sky(width, height, out.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise PrtError("prth_make_sky: %d" % rc)
+    return out
+
+
+class Renderer:
+    """One prt context (one HIP device).  Method names follow the C ABI one to one."""
+
+    def __init__(self, config, device=0):
+        self.lib = load_library()
+        self.ctx = C.c_void_p()
+        rc = self.lib.prt_create(device, C.byref(config), C.byref(self.ctx))
+        if rc:
+            raise PrtError("prt_create failed (%d): %s" % (rc, self.lib.prt_last_global_error().decode()))
+        self.width = self.height = self.rows = 0
+
+    def _chk(self, rc, what):
+        if rc:
+            raise PrtError("%s failed (%d): %s" % (what, rc, self.lib.prt_last_error(self.ctx).decode()))
+
+    def upload_scene(self, scene):
+        desc = scene.desc if isinstance(scene, HostScene) else scene
+        self._chk(self.lib.prt_upload_scene(self.ctx, C.byref(desc)), "prt_upload_scene")
+
+    def set_camera(self, cam):
+        self._chk(self.lib.prt_set_camera(self.ctx, C.byref(cam)), "prt_set_camera")
+
+    def upload_envmap(self, rgb):
+        rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+        self._chk(self.lib.prt_upload_envmap(self.ctx, rgb.ctypes.data_as(C.c_void_p), rgb.shape[1], rgb.shape[0]),
+                  "prt_upload_envmap")
+
+    def resize(self, width, height):
+        self._chk(self.lib.prt_resize(self.ctx, width, height), "prt_resize")
+        self.width, self.height, self.rows = width, height, height
+
+    def set_tile(self, width, full_height, row0, rows):
+        self._chk(self.lib.prt_set_tile(self.ctx, width, full_height, row0, rows), "prt_set_tile")
+        self.width, self.height, self.rows = width, full_height, rows
+
+    def reset(self):
+        self._chk(self.lib.prt_reset(self.ctx), "prt_reset")
+
+    def render_frames(self, seeds, first_frame=1):
+        seeds = np.ascontiguousarray(seeds, dtype=np.int32)
+        self._chk(self.lib.prt_render_frames(self.ctx, first_frame, len(seeds) // 2, seeds.ctypes.data_as(C.c_void_p)),
+                  "prt_render_frames")
+
+    def render_spp(self, spp, seeds):
+        seeds = np.ascontiguousarray(seeds, dtype=np.int32)
+        used = C.c_uint32(0)
+        self._chk(self.lib.prt_render_spp(self.ctx, spp, len(seeds) // 2, seeds.ctypes.data_as(C.c_void_p), C.byref(used)),
+                  "prt_render_spp")
+        return used.value
+
+    def synchronize(self):
+        self._chk(self.lib.prt_synchronize(self.ctx), "prt_synchronize")
+
+    def read_framebuffer(self):
+        out = np.zeros((self.rows, self.width, 4), dtype=np.float32)
+        self._chk(self.lib.prt_read_framebuffer(self.ctx, out.ctypes.data_as(C.c_void_p)), "prt_read_framebuffer")
+        return out
+
+    def copy_framebuffer_to_device(self, device_ptr):
+        self._chk(self.lib.prt_copy_framebuffer_to_device(self.ctx, C.c_void_p(device_ptr)), "prt_copy_framebuffer_to_device")
+
+    def read_state(self):
+        out = np.zeros(self.rows * self.width, dtype=np.dtype(PATH_STATE_DTYPE))
+        self._chk(self.lib.prt_read_state(self.ctx, out.ctypes.data_as(C.c_void_p)), "prt_read_state")
+        return out
+
+    def write_state(self, state):
+        state = np.ascontiguousarray(state)
+        assert state.dtype.itemsize == 112 and state.size == self.rows * self.width
+        self._chk(self.lib.prt_write_state(self.ctx, state.ctypes.data_as(C.c_void_p)), "prt_write_state")
+
+    def set_stream(self, hip_stream_ptr):
+        self._chk(self.lib.prt_set_stream(self.ctx, C.c_void_p(hip_stream_ptr)), "prt_set_stream")
+
+    def stats(self):
+        st = Stats()
+        self._chk(self.lib.prt_get_stats(self.ctx, C.byref(st)), "prt_get_stats")
+        return st
+
+    def counts(self, spp=0):
+        st = Stats()
+        self._chk(self.lib.prt_query_counts(self.ctx, spp, C.byref(st)), "prt_query_counts")
+        return st
+
+    def close(self):
+        if getattr(self, "ctx", None) and self.ctx.value:
+            self.lib.prt_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

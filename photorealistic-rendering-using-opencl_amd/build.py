@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Builds libprt.so in-tree: hipcc --offload-arch=gfx950 for the kernels + C-ABI, host C++ for the
+scene/camera/OBJ/BVH model.  -ffp-contract=off everywhere: the arithmetic contract of
+include/prt_detmath.h forbids implicit fma contraction on both host and device."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+HOSTCXX = os.environ.get("CXX", "g++")
+
+COMMON = ["-std=c++17", "-O3", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall",
+          "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(CSRC, "host"), "-I" + os.path.join(CSRC, "hip")]
+
+HOST_SOURCES = ["host/scene.cpp", "host/camera.cpp", "host/model_loader.cpp", "host/bvh.cpp", "host/host_capi.cpp"]
+HIP_SOURCES = ["hip/prt_api.cpp", "hip/pt_kernels.hip"]
+
+
+def newer(src, obj, deps):
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    return any(os.path.getmtime(d) > t for d in [src] + deps)
+
+
+def run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        sys.stderr.write("FAILED: %s\n%s\n" % (" ".join(cmd), r.stdout[-8000:]))
+        raise SystemExit(1)
+    return r.stdout
+
+
+def build(verbose=False, extra_hip_flags=()):
+    os.makedirs(OBJ, exist_ok=True)
+    headers = []
+    for d, _, files in os.walk(CSRC):
+        headers += [os.path.join(d, f) for f in files if f.endswith(".h")]
+    headers += [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include"))]
+    objs = []
+    for s in HOST_SOURCES + HIP_SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(OBJ, s.replace("/", "_") + ".o")
+        objs.append(obj)
+        if not newer(src, obj, headers):
+            continue
+        if s in HIP_SOURCES:
+            cmd = [HIPCC] + COMMON + ["-x", "hip", "--offload-arch=" + ARCH] + list(extra_hip_flags)
+        else:
+            cmd = [HOSTCXX] + COMMON
+        cmd += ["-c", src, "-o", obj]
+        out = run(cmd)
+        if verbose and out.strip():
+            print(out)
+    lib = os.path.join(HERE, "libprt.so")
+    if (not os.path.exists(lib)) or any(os.path.getmtime(o) > os.path.getmtime(lib) for o in objs):
+        run([HIPCC, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", lib] + objs)
+    return lib
+
+
+if __name__ == "__main__":
+    flags = [a for a in sys.argv[1:] if a.startswith("-")]
+    print(build(verbose=True, extra_hip_flags=flags))

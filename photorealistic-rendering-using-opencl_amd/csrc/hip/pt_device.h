@@ -1,0 +1,1068 @@
+// pt_device.h -- device functions of the MI355X path-tracing integrator (gfx950, wave64).
+//
+// One work-item owns one pixel and advances it by one path SEGMENT per frame, exactly like the
+// reference's render_kernel (kernels/main.cl:66-163) -- but the frame loop runs INSIDE the kernel
+// with the path state in registers, so the 112 B/px state round trip and the 16 B/px image write
+// of the reference happen once per launch instead of once per frame.  Seeds are re-derived per
+// (x, y, frame, seed pair) as in main.cl:108-109, which is what makes pixels independent and the
+// batching legal.
+//
+// Arithmetic contract: every floating-point value is produced by the same sequence of IEEE
+// binary32 operations as the reference expression it cites (component-wise vectors, left to
+// right, no contraction: the file is compiled with -ffp-contract=off) with include/prt_detmath.h
+// as the OpenCL built-in library.  That is what makes the output bit-identical to the CPU
+// oracle; do not "simplify" an expression here without re-reading the cited reference line.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "prt_detmath.h"
+#include "prt_types.h"
+#include "pt_layout.h"
+
+namespace prt {
+namespace dev {
+
+#define PT_EPS 1e-5f
+#define PT_INF 2e1f
+#define PT_PI 3.1415926535897932384626433832795f
+#define PT_TWO_PI 6.283185307179586476925286766559f
+#define PT_INV_PI 0.3183098861837906715377675267450f
+#define PT_INV_TWO_PI 0.1591549430918953357688837633725f
+#define PT_INV_FOUR_PI 0.0795774715459476678844418816863f
+
+#define PT_DEV __device__ __forceinline__
+
+struct f3 { float x, y, z; };
+PT_DEV f3 F3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+PT_DEV f3 splat(float s) { return F3(s, s, s); }
+PT_DEV f3 operator+(f3 a, f3 b) { return F3(a.x + b.x, a.y + b.y, a.z + b.z); }
+PT_DEV f3 operator-(f3 a, f3 b) { return F3(a.x - b.x, a.y - b.y, a.z - b.z); }
+PT_DEV f3 operator*(f3 a, f3 b) { return F3(a.x * b.x, a.y * b.y, a.z * b.z); }
+PT_DEV f3 operator*(f3 a, float s) { return F3(a.x * s, a.y * s, a.z * s); }
+PT_DEV f3 operator/(f3 a, float s) { return F3(a.x / s, a.y / s, a.z / s); }
+PT_DEV f3 operator-(f3 a) { return F3(-a.x, -a.y, -a.z); }
+PT_DEV float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+PT_DEV f3 cross(f3 a, f3 b) { return F3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+PT_DEV float length(f3 a) { return prt_sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+PT_DEV f3 normalize(f3 a) { float inv = 1.0f / prt_sqrt(a.x * a.x + a.y * a.y + a.z * a.z); return F3(a.x * inv, a.y * inv, a.z * inv); }
+PT_DEV f3 ld3(const float* p) { return F3(p[0], p[1], p[2]); }
+PT_DEV f3 vexp(f3 a) { return F3(prt_exp(a.x), prt_exp(a.y), prt_exp(a.z)); }
+PT_DEV float fmax3(f3 v) { return prt_fmax(prt_fmax(v.x, v.y), v.z); }
+PT_DEV float avg3(f3 v) { return (v.x * 1.0f + v.y * 1.0f + v.z * 1.0f) * 0.3333333333333333333333333333333333333333333333f; }
+
+// min/max for the slab test only.  The operands there are compared with <=, > afterwards, so the
+// sign of a zero result is irrelevant, and a NaN operand (0 * inf) must be ignored exactly like
+// OpenCL fmin/fmax do -- which is what v_min_f32 / v_max_f32 implement in IEEE mode.
+PT_DEV float hw_min(float a, float b) { return __builtin_fminf(a, b); }
+PT_DEV float hw_max(float a, float b) { return __builtin_fmaxf(a, b); }
+
+struct Rng { unsigned s0, s1; };
+PT_DEV float next1D(Rng& r) {                                   // kernels/prng/prng.cl:5-16
+    r.s0 = 36969u * (r.s0 & 65535u) + (r.s0 >> 16);
+    r.s1 = 18000u * (r.s1 & 65535u) + (r.s1 >> 16);
+    unsigned ires = (r.s0 << 16) + r.s1;
+    return (prt_u2f((ires & 0x007fffffu) | 0x40000000u) - 2.0f) * 0.5f;
+}
+
+struct Frame { f3 normal, tangent, bitangent; };
+PT_DEV Frame make_frame(f3 n) {                                 // kernels/header.cl:179-192
+    Frame f;
+    float sn = prt_copysign(1.0f, n.z);
+    float a = -1.0f / (sn + n.z);
+    float b = n.x * n.y * a;
+    f.normal = n;
+    f.tangent = F3(1.0f + sn * n.x * n.x * a, sn * b, -sn * n.x);
+    f.bitangent = F3(b, sn + n.y * n.y * a, -n.y);
+    return f;
+}
+PT_DEV f3 to_local(const Frame& f, f3 p) { return F3(dot(f.tangent, p), dot(f.bitangent, p), dot(f.normal, p)); }
+PT_DEV f3 to_global(const Frame& f, f3 p) { return f.tangent * p.x + f.bitangent * p.y + f.normal * p.z; }
+
+struct Ray {
+    f3 origin, dir, normal, pos;
+    float t;
+    bool backside;
+    float time;
+};
+
+struct Event {                                                   // SurfaceScatterEvent, header.cl:208-215
+    f3 wi, wo, weight;
+    float pdf;
+    unsigned sampledLobe;
+    Frame frame;
+};
+
+struct Mat {                                                     // Material, header.cl:219-234
+    f3 color, eta, k;
+    float roughness;
+    unsigned t, lobes, dist;
+};
+PT_DEV Mat load_mat(const DevMaterial* m) {
+    Mat r;
+    r.color = ld3(m->color); r.roughness = m->roughness;
+    r.eta = ld3(m->eta); r.k = ld3(m->k);
+    unsigned b = m->bits;
+    r.t = b & 0xffffu; r.lobes = (b >> 16) & 0xffu; r.dist = b >> 24;
+    return r;
+}
+
+// ---- sampling warps, kernels/utils.cl:92-152 ------------------------------------------------
+PT_DEV f3 uniform_sphere(float xi_x, float xi_y) {
+    float phi = xi_x * PT_TWO_PI;
+    float z = xi_y * 2.0f - 1.0f;
+    float r = prt_sqrt(prt_fmax(1.0f - z * z, 0.0f));
+    return F3(prt_cos(phi) * r, prt_sin(phi) * r, z);
+}
+PT_DEV f3 cosine_hemisphere(float xi_x, float xi_y) {
+    float phi = xi_x * PT_TWO_PI;
+    float r = prt_sqrt(xi_y);
+    return F3(prt_cos(phi) * r, prt_sin(phi) * r, prt_sqrt(prt_fmax(1.0f - xi_y, 0.0f)));
+}
+PT_DEV bool check_reflection(f3 wi, f3 wo) {                     // utils.cl:50-52
+    return prt_fabs(wi.z * wo.z - wi.x * wo.x - wi.y * wo.y - 1.0f) < 1e-3f;
+}
+PT_DEV bool check_refraction(f3 wi, f3 wo, float eta, float cosThetaT) {   // utils.cl:54-58
+    float dotP = -wi.x * wo.x * eta - wi.y * wo.y * eta - prt_copysign(cosThetaT, wi.z) * wo.z;
+    return prt_fabs(dotP - 1.0f) < 1e-3f;
+}
+
+// ---- camera, kernels/camera.cl:17-66 ---------------------------------------------------------
+PT_DEV Ray create_cam_ray(int cx, int cy, int width, int height, const DevCamera& cam, Rng& rng) {
+    f3 view = normalize(ld3(cam.view));
+    f3 up = normalize(ld3(cam.up));
+    f3 hAxis = normalize(cross(view, up));
+    f3 vAxis = normalize(cross(hAxis, view));
+    f3 position = ld3(cam.position);
+    f3 middle = position + view;
+    f3 horizontal = hAxis * prt_tan(cam.fov[0] * 0.5f * (PT_PI / 180));
+    f3 vertical = vAxis * prt_tan(cam.fov[1] * -0.5f * (PT_PI / 180));
+    int pixelx = cx;
+    int pixely = height - cy - 1;
+    float sx = (float)pixelx / (width - 1.0f);
+    float sy = (float)pixely / (height - 1.0f);
+    f3 onPlane = middle + (horizontal * ((2 * sx) - 1)) + (vertical * ((2 * sy) - 1));
+    f3 onImagePlane = position + ((onPlane - position) * cam.focalDistance);
+    f3 aperturePoint;
+    if (cam.apertureRadius > 0.00001f) {
+        float random1 = next1D(rng);
+        float random2 = next1D(rng);
+        float angle = 2 * PT_PI * random1;
+        float distance = cam.apertureRadius * prt_sqrt(random2);
+        float apertureX = prt_cos(angle) * distance;
+        float apertureY = prt_sin(angle) * distance;
+        aperturePoint = position + (hAxis * apertureX) + (vAxis * apertureY);
+    } else {
+        aperturePoint = position;
+    }
+    Ray ray;
+    ray.backside = false;
+    ray.origin = aperturePoint;
+    ray.dir = normalize(onImagePlane - aperturePoint);
+    ray.time = next1D(rng);
+    ray.normal = splat(0.0f);
+    ray.pos = splat(0.0f);
+    ray.t = 0.0f;
+    return ray;
+}
+
+// ---- BVH, kernels/geometry/bvh.cl + triangle.cl ------------------------------------------------
+struct RayPre { float ix, iy, iz, sx, sy, sz; bool nx, ny, nz; };
+PT_DEV RayPre ray_pre(const Ray& ray) {                          // bvh.cl:4-13 hoisted out of the node loop
+    RayPre p;
+    p.ix = prt_recip(ray.dir.x); p.iy = prt_recip(ray.dir.y); p.iz = prt_recip(ray.dir.z);
+    p.sx = -ray.origin.x * p.ix; p.sy = -ray.origin.y * p.iy; p.sz = -ray.origin.z * p.iz;
+    p.nx = ray.dir.x < 0.0f; p.ny = ray.dir.y < 0.0f; p.nz = ray.dir.z < 0.0f;
+    return p;
+}
+
+struct TriHit { float u, v, w; unsigned slot; };
+
+// triangle.cl:4-43; `best_t` is ray->t.  The smooth normal (triangle.cl:30-34) is deferred to the
+// end of the traversal: it only depends on (u, v, w, slot) of the last accepted hit.
+PT_DEV bool hit_triangle(const TriGeom* __restrict__ tg, unsigned slot, const Ray& ray, float& best_t, TriHit& th) {
+    const float4* q = reinterpret_cast<const float4*>(tg + slot);
+    const float4 a = q[0], b = q[1], c4 = q[2];
+    const f3 p0 = F3(a.x, a.y, a.z), e1 = F3(a.w, b.x, b.y), e2 = F3(b.z, b.w, c4.x), n = F3(c4.y, c4.z, c4.w);
+    f3 c = p0 - ray.origin;
+    f3 r = cross(ray.dir, c);
+    float inv_det = prt_recip(dot(n, ray.dir));
+    float u = dot(r, e2) * inv_det;
+    float v = dot(r, e1) * inv_det;
+    float w = 1.0f - u - v;
+    if (u >= 0 && v >= 0 && w >= 0) {
+        float t = dot(n, c) * inv_det;
+        if (t > PT_EPS && t < best_t) {
+            best_t = t;
+            th.u = u; th.v = v; th.w = w; th.slot = slot;
+            return true;
+        }
+    }
+    return false;
+}
+
+#ifndef PT_STACK_DEPTH
+#define PT_STACK_DEPTH 64      // the reference's closest-hit stack size (bvh.cl:131); deeper trees spill to `overflow`
+#endif
+
+// One body for bvh.cl:132-206 (closest hit) and :43-114 (any hit).  Returns true if (closest)
+// a triangle was accepted / (any) a triangle closer than ray.t exists.  Same visiting order as
+// the reference: both children's boxes are tested against the CURRENT ray.t before either leaf
+// is tested; leaf children are tested immediately, left first; of two inner children the nearer
+// (by entry distance, ties -> left) is followed and the other pushed.
+template <bool ANY_HIT>
+PT_DEV bool traverse(const DevScene& sc, const Ray& ray, float& best_t, TriHit& th, unsigned* stack) {
+    const RayPre p = ray_pre(ray);
+    bool found = false;
+    if (sc.root_is_leaf) {
+        for (unsigned i = sc.root_leaf_first; i < sc.root_leaf_first + sc.root_leaf_count; ++i) {
+            if (hit_triangle(sc.tri_geom, i, ray, best_t, th)) { found = true; if (ANY_HIT) return true; }
+        }
+        return found;
+    }
+    unsigned node = 0;
+    int sp = 0;
+    for (;;) {
+        const float4* q = reinterpret_cast<const float4*>(sc.pairs + node);
+        const float4 b0 = q[0], b1 = q[1], b2 = q[2];
+        const uint4 meta = *reinterpret_cast<const uint4*>(q + 3);
+        // child 0: x = b0.xy, y = b0.zw, z = b1.xy ; child 1: x = b1.zw, y = b2.xy, z = b2.zw
+        float e0x = prt_fma(p.nx ? b0.y : b0.x, p.ix, p.sx), x0x = prt_fma(p.nx ? b0.x : b0.y, p.ix, p.sx);
+        float e0y = prt_fma(p.ny ? b0.w : b0.z, p.iy, p.sy), x0y = prt_fma(p.ny ? b0.z : b0.w, p.iy, p.sy);
+        float e0z = prt_fma(p.nz ? b1.y : b1.x, p.iz, p.sz), x0z = prt_fma(p.nz ? b1.x : b1.y, p.iz, p.sz);
+        float e1x = prt_fma(p.nx ? b1.w : b1.z, p.ix, p.sx), x1x = prt_fma(p.nx ? b1.z : b1.w, p.ix, p.sx);
+        float e1y = prt_fma(p.ny ? b2.y : b2.x, p.iy, p.sy), x1y = prt_fma(p.ny ? b2.x : b2.y, p.iy, p.sy);
+        float e1z = prt_fma(p.nz ? b2.w : b2.z, p.iz, p.sz), x1z = prt_fma(p.nz ? b2.z : b2.w, p.iz, p.sz);
+        const float entry0 = hw_max(e0x, hw_max(e0y, hw_max(e0z, PT_EPS)));
+        const float exit0 = hw_min(x0x, hw_min(x0y, hw_min(x0z, best_t)));
+        const float entry1 = hw_max(e1x, hw_max(e1y, hw_max(e1z, PT_EPS)));
+        const float exit1 = hw_min(x1x, hw_min(x1y, hw_min(x1z, best_t)));
+        bool go0 = entry0 <= exit0, go1 = entry1 <= exit1;
+        if (go0 && meta.y != 0xFFFFFFFFu) {                      // left child is a leaf
+            for (unsigned i = meta.x; i < meta.x + meta.y; ++i)
+                if (hit_triangle(sc.tri_geom, i, ray, best_t, th)) { found = true; if (ANY_HIT) return true; }
+            go0 = false;
+        }
+        if (go1 && meta.w != 0xFFFFFFFFu) {
+            for (unsigned i = meta.z; i < meta.z + meta.w; ++i)
+                if (hit_triangle(sc.tri_geom, i, ray, best_t, th)) { found = true; if (ANY_HIT) return true; }
+            go1 = false;
+        }
+        if (go0 != go1) {
+            node = go0 ? meta.x : meta.z;
+        } else if (go0) {
+            unsigned nearc = meta.x, farc = meta.z;
+            if (entry0 > entry1) { nearc = meta.z; farc = meta.x; }
+            if (sp < PT_STACK_DEPTH) stack[sp] = farc;
+            ++sp;
+            node = nearc;
+        } else {
+            if (sp == 0) break;
+            --sp;
+            node = stack[sp < PT_STACK_DEPTH ? sp : PT_STACK_DEPTH - 1];
+        }
+    }
+    return found;
+}
+
+// ---- sphere / quad, kernels/geometry/sphere.cl:5-41, quad.cl:11-38 ------------------------------
+PT_DEV bool hit_sphere(const DevSphere& s, const Ray& ray, float& best_t) {
+    f3 p = ray.origin - ld3(s.pos);
+    float B = dot(p, ray.dir);
+    float C = dot(p, p) - s.radius * s.radius;
+    float detSq = B * B - C;
+    if (detSq >= 0.0f) {
+        float det = prt_sqrt(detSq);
+        float t = -B - det;
+        if (t < best_t && t > PT_EPS) { best_t = t; return true; }
+        t = -B + det;
+        if (t < best_t && t > PT_EPS) { best_t = t; return true; }
+    }
+    return false;
+}
+PT_DEV bool hit_quad(const DevQuad& qd, const Ray& ray, float& best_t, f3& q_out) {
+    const f3 normal = ld3(qd.normal);
+    float nDotW = dot(normal, ray.dir);
+    if (nDotW <= 1e-5f) return false;            // reference: (double)nDotW < 1e-5  <=>  nDotW <= 1e-5f in binary32
+    const f3 anchor = ld3(qd.anchor);
+    float rt = dot(normal, anchor - ray.origin) / nDotW;
+    if (rt <= PT_EPS || rt >= best_t) return false;
+    f3 q = ray.origin + ray.dir * rt;            // origin + rt * dir
+    f3 v = q - anchor;
+    float l0 = dot(v, ld3(qd.edge0)) / qd.e0e0;
+    float l1 = dot(v, ld3(qd.edge1)) / qd.e1e1;
+    if (l0 < 0.0f || l0 > 1.0f || l1 < 0.0f || l1 > 1.0f) return false;
+    best_t = rt;
+    q_out = q;
+    return true;
+}
+
+// ---- intersect_scene, kernels/intersect.cl:158-236 -----------------------------------------------
+// in: ray.origin/dir/normal.  out: ray.t/normal/pos/backside, mesh_id (-1 = OBJ or nothing).
+PT_DEV bool intersect_scene(const DevScene& sc, Ray& ray, int& mesh_id, unsigned* stack) {
+    float t = PT_INF;
+    mesh_id = -1;
+    TriHit th;
+    th.u = th.v = th.w = 0.0f; th.slot = 0;
+    if (traverse<false>(sc, ray, t, th, stack)) {
+        const float4* nq = reinterpret_cast<const float4*>(sc.tri_nrm + th.slot);
+        const float4 a = nq[0], b = nq[1], c = nq[2];
+        ray.normal = F3(a.x, a.y, a.z) * th.w + F3(b.x, b.y, b.z) * th.u + F3(c.x, c.y, c.z) * th.v;
+    }
+    ray.normal = normalize(ray.normal);
+    ray.pos = ray.origin + ray.dir * t;
+    if (sc.geom_flags & PRT_GEOM_SPHERE) {
+        for (unsigned i = 0; i < sc.n_spheres; ++i) {
+            const DevSphere s = sc.spheres[i];
+            if (hit_sphere(s, ray, t)) {
+                ray.pos = ray.origin + ray.dir * t;
+                ray.normal = normalize(ray.pos - ld3(s.pos));
+                mesh_id = (int)i;
+            }
+        }
+    }
+    if (sc.geom_flags & PRT_GEOM_QUAD) {
+        for (unsigned i = 0; i < sc.n_quads; ++i) {
+            f3 q;
+            if (hit_quad(sc.quads[i], ray, t, q)) {
+                ray.backside = false;
+                ray.normal = ld3(sc.quads[i].normal);
+                ray.pos = q;
+                mesh_id = (int)(sc.quad_mesh_base + i);
+            }
+        }
+    }
+    bool nTrans = true;
+    if (sc.ntrans_mask) nTrans = ((sc.mats[mesh_id + 1].bits & 0xffffu) & ~sc.ntrans_mask) != 0;
+    ray.t = t;
+    ray.backside = dot(ray.normal, ray.dir) > 0.0f;
+    if (nTrans && ray.backside) ray.normal = -ray.normal;
+    return t < PT_INF;
+}
+
+// ---- shadow, kernels/intersect.cl:94-152: true = unoccluded --------------------------------------
+PT_DEV bool shadow(const DevScene& sc, const f3 origin, const f3 dir, const float maxDist, unsigned* stack) {
+    Ray ray;
+    ray.origin = origin; ray.dir = dir; ray.t = maxDist;
+    float t = maxDist;
+    TriHit th;
+    if (traverse<true>(sc, ray, t, th, stack)) return false;
+    if (sc.geom_flags & PRT_GEOM_SPHERE) {
+        for (unsigned i = 0; i < sc.n_spheres; ++i)
+            if (hit_sphere(sc.spheres[i], ray, t)) return false;     // an accepted hit always has t < maxDist
+    }
+    if (sc.geom_flags & PRT_GEOM_QUAD) {
+        for (unsigned i = 0; i < sc.n_quads; ++i) {
+            f3 q;
+            if (hit_quad(sc.quads[i], ray, t, q)) return false;
+        }
+    }
+    return true;
+}
+
+// ---- light sampling, kernels/geometry/{sphere.cl:59-88, quad.cl:40-62, geometry.cl:11-52} -----------
+struct LightSample { f3 d; float dist, pdf; };
+
+PT_DEV float sphere_direct_pdf(const DevSphere& s, f3 p) {
+    float dist = length(ld3(s.pos) - p);
+    float cosTheta = prt_sqrt(prt_fmax(dist * dist - s.radius * s.radius, 0.0f)) / dist;
+    return PT_INV_TWO_PI / (1.0f - cosTheta);
+}
+PT_DEV bool sphere_sample_direct(const DevSphere& s, f3 p, LightSample& ls, Rng& rng) {
+    f3 L = ld3(s.pos) - p;
+    float d = length(L);
+    float C = d * d - s.radius * s.radius;
+    if (C <= 0.0f) return false;
+    L = normalize(L);
+    float cosTheta = prt_sqrt(C) / d;
+    float xi_x = next1D(rng), xi_y = next1D(rng);
+    (void)xi_x;                                  // the cap's azimuth is sampled and then discarded (sphere.cl:76-84)
+    float z = xi_y * (1.0f - cosTheta) + cosTheta;
+    float B = d * z;
+    float det = prt_sqrt(prt_fmax(B * B - C, 0.0f));
+    ls.dist = B - det;
+    Frame frame = make_frame(L);
+    ls.d = to_global(frame, splat(cosTheta));
+    ls.pdf = PT_INV_TWO_PI / (1.0f - cosTheta);
+    return true;
+}
+PT_DEV bool quad_sample_direct(const DevQuad& qd, f3 p, LightSample& ls, Rng& rng) {
+    const f3 base = ld3(qd.base), normal = ld3(qd.normal);
+    if (dot(normal, p - base) <= 0.0f) return false;
+    float xi_x = next1D(rng), xi_y = next1D(rng);
+    f3 q = base + ld3(qd.edge0) * xi_x + ld3(qd.edge1) * xi_y;
+    ls.d = q - p;
+    float rSq = dot(ls.d, ls.d);
+    ls.dist = prt_sqrt(rSq);
+    ls.d = ls.d / ls.dist;
+    float cosTheta = -dot(normal, ls.d);
+    ls.pdf = rSq / (cosTheta * qd.area);
+    return true;
+}
+PT_DEV float quad_direct_pdf(const DevQuad& qd, f3 dir, f3 p) {
+    const f3 normal = ld3(qd.normal);
+    float cosTheta = prt_fabs(dot(normal, dir));
+    float t = dot(normal, ld3(qd.base) - p) / dot(normal, dir);
+    return t * t / (cosTheta * qd.area);
+}
+// directPdf of the mesh that a probe ray hit (mesh_id >= 0)
+PT_DEV float direct_pdf_mesh(const DevScene& sc, int mesh_id, f3 dir, f3 p) {
+    if ((sc.geom_flags & PRT_GEOM_SPHERE) && (unsigned)mesh_id < sc.n_spheres) return sphere_direct_pdf(sc.spheres[mesh_id], p);
+    if ((sc.geom_flags & PRT_GEOM_QUAD) && (unsigned)mesh_id >= sc.quad_mesh_base) return quad_direct_pdf(sc.quads[mesh_id - sc.quad_mesh_base], dir, p);
+    return 0.0f;
+}
+PT_DEV bool sample_light0(const DevScene& sc, f3 p, LightSample& ls, Rng& rng) {
+    if (sc.light_sphere != 0xFFFFFFFFu) return sphere_sample_direct(sc.spheres[sc.light_sphere], p, ls, rng);
+    if (sc.light_quad != 0xFFFFFFFFu) return quad_sample_direct(sc.quads[sc.light_quad], p, ls, rng);
+    return false;
+}
+
+// ---- Fresnel, kernels/bxdf/Fresnel.cl:6-67 ----------------------------------------------------------
+PT_DEV float conductor_reflectance(float eta, float k, float cosThetaI) {
+    float cosThetaISq = cosThetaI * cosThetaI;
+    float sinThetaISq = prt_fmax(1.0f - cosThetaISq, 0.0f);
+    float sinThetaIQu = sinThetaISq * sinThetaISq;
+    float innerTerm = eta * eta - k * k - sinThetaISq;
+    float aSqPlusBSq = prt_sqrt(prt_fmax(innerTerm * innerTerm + 4.0f * eta * eta * k * k, 0.0f));
+    float a = prt_sqrt(prt_fmax((aSqPlusBSq + innerTerm) * 0.5f, 0.0f));
+    float Rs = ((aSqPlusBSq + cosThetaISq) - (2.0f * a * cosThetaI)) / ((aSqPlusBSq + cosThetaISq) + (2.0f * a * cosThetaI));
+    float Rp = ((cosThetaISq * aSqPlusBSq + sinThetaIQu) - (2.0f * a * cosThetaI * sinThetaISq)) /
+               ((cosThetaISq * aSqPlusBSq + sinThetaIQu) + (2.0f * a * cosThetaI * sinThetaISq));
+    return 0.5f * (Rs + Rs * Rp);
+}
+PT_DEV f3 conductor_reflectance3(f3 eta, f3 k, float c) {
+    return F3(conductor_reflectance(eta.x, k.x, c), conductor_reflectance(eta.y, k.y, c), conductor_reflectance(eta.z, k.z, c));
+}
+PT_DEV float dielectric_reflectance(float eta, float cosThetaI, float& cosThetaT) {
+    if (cosThetaI < 0.0f) { eta = 1.0f / eta; cosThetaI = -cosThetaI; }
+    float sinThetaTSq = eta * eta * (1.0f - cosThetaI * cosThetaI);
+    if (sinThetaTSq > 1.0f) { cosThetaT = 0.0f; return 1.0f; }
+    cosThetaT = prt_sqrt(prt_fmax(1.0f - sinThetaTSq, 0.0f));
+    float Rs = (eta * cosThetaI - cosThetaT) / (eta * cosThetaI + cosThetaT);
+    float Rp = (eta * cosThetaT - cosThetaI) / (eta * cosThetaT + cosThetaI);
+    return (Rs * Rs + Rp * Rp) * 0.5f;
+}
+
+// ---- microfacet, kernels/bxdf/microfacet.cl:11-108 ----------------------------------------------------
+PT_DEV float roughness_to_alpha(unsigned dist, float roughness) {
+    roughness = prt_fmax(roughness, 1e-3f);
+    if (dist & PRT_DIST_PHONG) return 2.0f / (roughness * roughness) - 2.0f;
+    return roughness;
+}
+PT_DEV float mf_D(unsigned dist, float alpha, f3 m) {
+    if (m.z <= 0.0f) return 0.0f;
+    if (dist & PRT_DIST_BECKMANN) {
+        float alphaSq = alpha * alpha, cosThetaSq = m.z * m.z;
+        float tanThetaSq = prt_fmax(1.0f - cosThetaSq, 0.0f) / cosThetaSq;
+        float cosThetaQu = cosThetaSq * cosThetaSq;
+        return PT_INV_PI * prt_exp(-tanThetaSq / alphaSq) / (alphaSq * cosThetaQu);
+    } else if (dist & PRT_DIST_PHONG) {
+        return (alpha + 2.0f) * PT_INV_TWO_PI * prt_pow(m.z, alpha);
+    } else if (dist & PRT_DIST_GGX) {
+        float alphaSq = alpha * alpha, cosThetaSq = m.z * m.z;
+        float tanThetaSq = prt_fmax(1.0f - cosThetaSq, 0.0f) / cosThetaSq;
+        float cosThetaQu = cosThetaSq * cosThetaSq;
+        float s = alphaSq + tanThetaSq;
+        return alphaSq * PT_INV_PI / (cosThetaQu * (s * s));   // pow(x, 2.0f) == x*x in prt_detmath.h
+    }
+    return 0.0f;
+}
+PT_DEV float mf_G1(unsigned dist, float alpha, f3 v, f3 m) {
+    if (dot(v, m) * v.z <= 0.0f) return 0.0f;
+    if (dist & PRT_DIST_BECKMANN) {
+        float cosThetaSq = v.z * v.z;
+        float tanTheta = prt_fabs(prt_sqrt(prt_fmax(1.0f - cosThetaSq, 0.0f)) / v.z);
+        float a = 1.0f / (alpha * tanTheta);
+        if (a < 1.6f) return (3.535f * a + 2.181f * a * a) / (1.0f + 2.276f * a + 2.577f * a * a);
+        return 1.0f;
+    } else if (dist & PRT_DIST_PHONG) {
+        float cosThetaSq = v.z * v.z;
+        float tanTheta = prt_fabs(prt_sqrt(prt_fmax(1.0f - cosThetaSq, 0.0f)) / v.z);
+        float a = prt_sqrt(0.5f * alpha + 1.0f) / tanTheta;
+        if (a < 1.6f) return (3.535f * a + 2.181f * a * a) / (1.0f + 2.276f * a + 2.577f * a * a);
+        return 1.0f;
+    } else if (dist & PRT_DIST_GGX) {
+        float alphaSq = alpha * alpha, cosThetaSq = v.z * v.z;
+        float tanThetaSq = prt_fmax(1.0f - cosThetaSq, 0.0f) / cosThetaSq;
+        return 2.0f / (1.0f + prt_sqrt(1.0f + alphaSq * tanThetaSq));
+    }
+    return 0.0f;
+}
+PT_DEV float mf_G(unsigned dist, float alpha, f3 i, f3 o, f3 m) { return mf_G1(dist, alpha, i, m) * mf_G1(dist, alpha, o, m); }
+PT_DEV float mf_pdf(unsigned dist, float alpha, f3 m) { return mf_D(dist, alpha, m) * m.z; }
+PT_DEV f3 mf_sample(unsigned dist, float alpha, float xi_x, float xi_y) {
+    float phi = xi_y * PT_TWO_PI;
+    float cosTheta = 0.0f;
+    if (dist & PRT_DIST_BECKMANN) {
+        float tanThetaSq = -alpha * alpha * prt_log(1.0f - xi_x);
+        cosTheta = 1.0f / prt_sqrt(1.0f + tanThetaSq);
+    } else if (dist & PRT_DIST_PHONG) {
+        cosTheta = prt_pow(xi_x, 1.0f / (alpha + 2.0f));
+    } else if (dist & PRT_DIST_GGX) {
+        float tanThetaSq = alpha * alpha * xi_x / (1.0f - xi_x);
+        cosTheta = 1.0f / prt_sqrt(1.0f + tanThetaSq);
+    }
+    float r = prt_sqrt(prt_fmax(1.0f - cosTheta * cosTheta, 0.0f));
+    return F3(prt_cos(phi) * r, prt_sin(phi) * r, cosTheta);
+}
+
+// ---- materials ------------------------------------------------------------------------------------------
+// Lambert.cl:4-31 (pdf: see oracle/pt_oracle.c LambertBSDF_pdf -- the reference build returns 0)
+PT_DEV bool lambert_sample(Event& e, const Mat& mat, Rng& rng) {
+    if (e.wi.z <= 0.0f) return false;
+    float xi_x = next1D(rng), xi_y = next1D(rng);
+    e.wo = cosine_hemisphere(xi_x, xi_y);
+    e.pdf = prt_fabs(e.wo.z) * PT_INV_PI;
+    e.weight = mat.color;
+    e.sampledLobe = PRT_LOBE_DIFFUSE_R;
+    return true;
+}
+PT_DEV f3 lambert_eval(const Event& e, const Mat& mat) {
+    if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return splat(0.0f);
+    return mat.color * PT_INV_PI * e.wo.z;
+}
+// Conductor.cl:4-29
+PT_DEV bool conductor_sample(Event& e, const Mat& mat) {
+    f3 F = conductor_reflectance3(mat.eta, mat.k, e.wi.z);
+    e.wo = F3(-e.wi.x, -e.wi.y, e.wi.z);
+    e.pdf = 1.0f;
+    e.weight = mat.color * F;
+    e.sampledLobe = PRT_LOBE_SPECULAR_R;
+    return true;
+}
+PT_DEV f3 conductor_eval(const Event& e, const Mat& mat) {
+    f3 F = conductor_reflectance3(mat.eta, mat.k, e.wi.z);
+    if (check_reflection(e.wi, e.wo)) return mat.color * F;
+    return splat(0.0f);
+}
+// RoughConductor.cl:4-62
+PT_DEV bool rough_conductor_sample(Event& e, const Mat& mat, Rng& rng) {
+    if (e.wi.z <= 0.0f) return false;
+    float alpha = roughness_to_alpha(mat.dist, mat.roughness);
+    float xi_x = next1D(rng), xi_y = next1D(rng);
+    f3 m = mf_sample(mat.dist, alpha, xi_x, xi_y);
+    float wiDotM = dot(e.wi, m);
+    e.wo = m * (2.0f * wiDotM) - e.wi;
+    if (wiDotM <= 0.0f || e.wo.z <= 0.0f) return false;
+    float G = mf_G(mat.dist, alpha, e.wi, e.wo, m);
+    float D = mf_D(mat.dist, alpha, m);
+    float mPdf = mf_pdf(mat.dist, alpha, m);
+    float pdf = mPdf * 0.25f / wiDotM;
+    float weight = wiDotM * G * D / (e.wi.z * mPdf);
+    f3 F = conductor_reflectance3(mat.eta, mat.k, wiDotM);
+    e.pdf = pdf;
+    e.weight = mat.color * F * weight;
+    e.sampledLobe = PRT_LOBE_GLOSSY_R;
+    return true;
+}
+PT_DEV f3 rough_conductor_eval(f3 wi, f3 wo, const Mat& mat) {
+    if (wi.z <= 0.0f || wo.z <= 0.0f) return splat(0.0f);
+    float alpha = roughness_to_alpha(mat.dist, mat.roughness);
+    f3 hr = normalize(wi + wo);
+    float cosThetaM = dot(wi, hr);
+    f3 F = conductor_reflectance3(mat.eta, mat.k, cosThetaM);
+    float G = mf_G(mat.dist, alpha, wi, wo, hr);
+    float D = mf_D(mat.dist, alpha, hr);
+    float fr = (G * D * 0.25f) / wi.z;
+    return mat.color * (F * fr);
+}
+PT_DEV float rough_conductor_pdf(f3 wi, f3 wo, const Mat& mat) {
+    if (wi.z <= 0.0f || wo.z <= 0.0f) return 0.0f;
+    float sampleAlpha = roughness_to_alpha(mat.dist, mat.roughness);
+    f3 hr = normalize(wi + wo);
+    return mf_pdf(mat.dist, sampleAlpha, hr) * 0.25f / dot(wi, hr);
+}
+// Dielectric.cl:30-37 == RoughDielectric.cl:55-62
+PT_DEV f3 absorb_weight(f3 weight, const Mat& mat, bool backside, float ray_t) {
+    const bool ABS1 = (mat.t & PRT_MAT_ABS_REFR) != 0, ABS2 = (mat.t & PRT_MAT_ABS_REFR2) != 0;
+    if (ABS1 | ABS2) {
+        weight = weight * (ABS2 ? mat.color : splat(1.0f));
+        if (backside) {
+            f3 c = ABS1 ? mat.color : splat(1.0f);
+            weight = weight * vexp(c * (-ray_t) * 10.0f);
+        } else {
+            weight = weight * splat(1.0f);
+        }
+    } else {
+        weight = weight * mat.color;
+    }
+    return weight;
+}
+// Dielectric.cl:4-87
+PT_DEV bool dielectric_sample(Event& e, const Mat& mat, bool backside, float ray_t, Rng& rng) {
+    const float eta = e.wi.z < 0.0f ? mat.eta.x : 1.0f / mat.eta.x;
+    float cosThetaT = 0.0f;
+    float F = dielectric_reflectance(eta, prt_fabs(e.wi.z), cosThetaT);
+    if (next1D(rng) < F) {
+        e.wo = F3(-e.wi.x, -e.wi.y, e.wi.z);
+        e.pdf = F;
+        e.sampledLobe = PRT_LOBE_SPECULAR_R;
+        e.weight = splat(F);
+    } else {
+        if (F == 1.0f) return false;
+        e.wo = F3(-e.wi.x * eta, -e.wi.y * eta, -prt_copysign(cosThetaT, e.wi.z));
+        e.pdf = 1.0f - F;
+        e.sampledLobe = PRT_LOBE_SPECULAR_T;
+        e.weight = splat(1.0f - F);
+    }
+    e.weight = absorb_weight(e.weight, mat, backside, ray_t);
+    return true;
+}
+PT_DEV f3 dielectric_eval(const Event& e, const Mat& mat) {
+    const float eta = e.wi.z < 0.0f ? mat.eta.x : 1.0f / mat.eta.x;
+    float cosThetaT = 0.0f;
+    float F = dielectric_reflectance(eta, prt_fabs(e.wi.z), cosThetaT);
+    if (e.wi.z * e.wo.z >= 0.0f) {
+        if (check_reflection(e.wi, e.wo)) return mat.color * F;
+        return splat(0.0f);
+    }
+    if (check_refraction(e.wi, e.wo, eta, cosThetaT)) return mat.color * (1.0f - F);
+    return splat(0.0f);
+}
+PT_DEV float dielectric_pdf(const Event& e, const Mat& mat) {
+    const float eta = e.wi.z < 0.0f ? mat.eta.x : 1.0f / mat.eta.x;
+    float cosThetaT = 0.0f;
+    float F = dielectric_reflectance(eta, prt_fabs(e.wi.z), cosThetaT);
+    if (e.wi.z * e.wo.z >= 0.0f) return check_reflection(e.wi, e.wo) ? F : 0.0f;
+    return check_refraction(e.wi, e.wo, eta, cosThetaT) ? 1.0f - F : 0.0f;
+}
+PT_DEV float dielectric_eta(const Event& e, const Mat& mat) {   // Dielectric.cl:82-87 == RoughDielectric.cl:132-137
+    if (e.wi.z * e.wo.z >= 0.0f) return 1.0f;
+    return e.wi.z < 0.0f ? mat.eta.x : 1.0f / mat.eta.x;
+}
+// RoughDielectric.cl:4-137
+PT_DEV float sgnE(float t) { return t < 0.0f ? -1.0f : 1.0f; }
+PT_DEV bool rough_dielectric_sample(Event& e, const Mat& mat, bool backside, float ray_t, Rng& rng) {
+    const float wiDotN = e.wi.z;
+    const float eta = e.wi.z < 0.0f ? mat.eta.x : 1.0f / mat.eta.x;
+    float sampleRoughness = (1.2f - 0.2f * prt_sqrt(prt_fabs(wiDotN))) * mat.roughness;
+    float alpha = roughness_to_alpha(mat.dist, mat.roughness);
+    float sampleAlpha = roughness_to_alpha(mat.dist, sampleRoughness);
+    float xi_x = next1D(rng), xi_y = next1D(rng);
+    f3 m = mf_sample(mat.dist, sampleAlpha, xi_x, xi_y);
+    float pm = mf_pdf(mat.dist, sampleAlpha, m);
+    if (pm < 1e-10f) return false;
+    float wiDotM = dot(e.wi, m);
+    float cosThetaT = 0.0f;
+    float F = dielectric_reflectance(1.0f / mat.eta.x, wiDotM, cosThetaT);
+    float etaM = wiDotM < 0.0f ? mat.eta.x : 1.0f / mat.eta.x;
+    bool reflect = next1D(rng) < F;
+    if (reflect) e.wo = m * (2.0f * wiDotM) - e.wi;
+    else e.wo = m * (etaM * wiDotM - sgnE(wiDotM) * cosThetaT) - e.wi * etaM;
+    float woDotN = e.wo.z;
+    bool reflected = wiDotN * woDotN > 0.0f;
+    if (reflected != reflect) return false;
+    float woDotM = dot(e.wo, m);
+    float G = mf_G(mat.dist, alpha, e.wi, e.wo, m);
+    float D = mf_D(mat.dist, alpha, m);
+    e.weight = splat(prt_fabs(wiDotM) * G * D / (prt_fabs(wiDotN) * pm));
+    if (reflect) {
+        e.pdf = F * pm * 0.25f / prt_fabs(wiDotM);
+        e.sampledLobe = PRT_LOBE_GLOSSY_R;
+    } else {
+        float s = eta * wiDotM + woDotM;
+        e.pdf = (1.0f - F) * pm * prt_fabs(woDotM) / (s * s);
+        e.sampledLobe = PRT_LOBE_GLOSSY_T;
+    }
+    e.weight = absorb_weight(e.weight, mat, backside, ray_t);
+    return true;
+}
+PT_DEV f3 rough_diel_half(const Event& e, float eta, bool reflect) {
+    if (reflect) return normalize(e.wi + e.wo) * sgnE(e.wi.z);
+    return -normalize(e.wi * eta + e.wo);
+}
+PT_DEV f3 rough_dielectric_eval(const Event& e, const Mat& mat) {
+    float wiDotN = e.wi.z, woDotN = e.wo.z;
+    bool reflect = wiDotN * woDotN >= 0.0f;
+    float alpha = roughness_to_alpha(mat.dist, mat.roughness);
+    const float eta = wiDotN < 0.0f ? mat.eta.x : 1.0f / mat.eta.x;
+    f3 m = rough_diel_half(e, eta, reflect);
+    float wiDotM = dot(e.wi, m), woDotM = dot(e.wo, m);
+    float cosThetaT = 0.0f;
+    float F = dielectric_reflectance(1.0f / mat.eta.x, wiDotM, cosThetaT);
+    float G = mf_G(mat.dist, alpha, e.wi, e.wo, m);
+    float D = mf_D(mat.dist, alpha, m);
+    float fx;
+    if (reflect) {
+        fx = (F * G * D * 0.25f) / prt_fabs(wiDotN);
+    } else {
+        float s = eta * wiDotM + woDotM;
+        fx = prt_fabs(wiDotM * woDotM) * (1.0f - F) * G * D / ((s * s) * prt_fabs(wiDotN));
+    }
+    return mat.color * fx;
+}
+PT_DEV float rough_dielectric_pdf(const Event& e, const Mat& mat) {
+    float wiDotN = e.wi.z, woDotN = e.wo.z;
+    bool reflect = wiDotN * woDotN >= 0.0f;
+    float sampleRoughness = (1.2f - 0.2f * prt_sqrt(prt_fabs(wiDotN))) * mat.roughness;
+    float sampleAlpha = roughness_to_alpha(mat.dist, sampleRoughness);
+    float eta = wiDotN < 0.0f ? mat.eta.x : 1.0f / mat.eta.x;
+    f3 m = rough_diel_half(e, eta, reflect);
+    float wiDotM = dot(e.wi, m), woDotM = dot(e.wo, m);
+    float cosThetaT = 0.0f;
+    float F = dielectric_reflectance(1.0f / mat.eta.x, wiDotM, cosThetaT);
+    float pm = mf_pdf(mat.dist, sampleAlpha, m);
+    if (reflect) return F * pm * 0.25f / prt_fabs(wiDotM);
+    float s = eta * wiDotM + woDotM;
+    return (1.0f - F) * pm * prt_fabs(woDotM) / (s * s);
+}
+// Coat.cl:4-112 (ior 1.3, thickness 1, sigmaA 0 -> avgTransmittance = exp(-0) = 1)
+#define PT_COAT_IOR 1.3f
+PT_DEV bool coat_sample(Event& e, const Mat& mat, Rng& rng) {
+    if (e.wi.z <= 0.0f) return false;
+    const float eta = 1.0f / PT_COAT_IOR;
+    const float avgTransmittance = 1.0f;
+    float cosThetaTi;
+    float Fi = dielectric_reflectance(eta, e.wi.z, cosThetaTi);
+    float specularProbability = Fi / (Fi + avgTransmittance * (1.0f - Fi));
+    if (next1D(rng) < specularProbability) {
+        e.wo = F3(-e.wi.x, -e.wi.y, e.wi.z);
+        e.pdf = specularProbability;
+        e.weight = splat(Fi / specularProbability);
+        e.sampledLobe = PRT_LOBE_SPECULAR_R;
+    } else {
+        f3 originalWi = e.wi;
+        e.wi = F3(originalWi.x * eta, originalWi.y * eta, cosThetaTi);
+        if (!rough_conductor_sample(e, mat, rng)) return false;
+        e.wi = originalWi;
+        float cosThetaTo;
+        float Fo = dielectric_reflectance(PT_COAT_IOR, e.wo.z, cosThetaTo);
+        if (Fo == 1.0f) return false;
+        float cosThetaSubstrate = e.wo.z;
+        e.wo = F3(e.wo.x * PT_COAT_IOR, e.wo.y * PT_COAT_IOR, cosThetaTo);
+        e.weight = e.weight * ((1.0f - Fi) * (1.0f - Fo));
+        e.weight = e.weight / (1.0f - specularProbability);
+        e.pdf *= 1.0f - specularProbability;
+        e.pdf *= eta * eta * cosThetaTo / cosThetaSubstrate;
+    }
+    return true;
+}
+PT_DEV f3 coat_eval(const Event& e, const Mat& mat) {
+    if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return splat(0.0f);
+    const float eta = 1.0f / PT_COAT_IOR;
+    float cosThetaTi;
+    float Fi = dielectric_reflectance(eta, e.wi.z, cosThetaTi);
+    if (check_reflection(e.wi, e.wo)) return splat(Fi);
+    float cosThetaTo;
+    float Fo = dielectric_reflectance(eta, e.wo.z, cosThetaTo);
+    f3 nwi = F3(e.wi.x * eta, e.wi.y * eta, prt_copysign(cosThetaTi, e.wi.z));
+    f3 nwo = F3(e.wo.x * eta, e.wo.y * eta, prt_copysign(cosThetaTo, e.wo.z));
+    f3 substrateF = rough_conductor_eval(nwi, nwo, mat);
+    float laplacian = eta * eta * e.wo.z / cosThetaTo;
+    return substrateF * (laplacian * (1.0f - Fi) * (1.0f - Fo));
+}
+PT_DEV float coat_pdf(const Event& e, const Mat& mat) {
+    if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return 0.0f;
+    const float eta = 1.0f / PT_COAT_IOR;
+    const float avgTransmittance = 1.0f;
+    float cosThetaTi;
+    float Fi = dielectric_reflectance(eta, e.wi.z, cosThetaTi);
+    float specularProbability = Fi / (Fi + avgTransmittance * (1.0f - Fi));
+    if (check_reflection(e.wi, e.wo)) return specularProbability;
+    float cosThetaTo;
+    dielectric_reflectance(eta, e.wo.z, cosThetaTo);
+    f3 nwi = F3(e.wi.x * eta, e.wi.y * eta, prt_copysign(cosThetaTi, e.wi.z));
+    f3 nwo = F3(e.wo.x * eta, e.wo.y * eta, prt_copysign(cosThetaTo, e.wo.z));
+    return rough_conductor_pdf(nwi, nwo, mat) * (1.0f - specularProbability) * eta * eta * prt_fabs(e.wo.z / cosThetaTo);
+}
+
+// ---- dispatch, kernels/bxdf/bxdf.cl:57-273.  MATS = compile-time ACTIVE_MATS (0 = run-time) ---------
+template <unsigned MATS>
+PT_DEV unsigned active_mats(const DevScene& sc) { return MATS ? MATS : sc.active_mats; }
+
+template <unsigned MATS>
+PT_DEV bool bsdf_sample2(const DevScene& sc, Event& e, const Ray& ray, const Mat& mat, Rng& rng) {
+    const unsigned am = active_mats<MATS>(sc);
+    const unsigned t = mat.t & am;
+    bool ok;
+    if (t & PRT_MAT_DIFF) ok = lambert_sample(e, mat, rng);
+    else if (t & PRT_MAT_COND) ok = conductor_sample(e, mat);
+    else if (t & PRT_MAT_ROUGH_COND) ok = rough_conductor_sample(e, mat, rng);
+    else if (t & PRT_MAT_DIEL) ok = dielectric_sample(e, mat, ray.backside, ray.t, rng);
+    else if (t & PRT_MAT_ROUGH_DIEL) ok = rough_dielectric_sample(e, mat, ray.backside, ray.t, rng);
+    else if (t & PRT_MAT_COAT) ok = coat_sample(e, mat, rng);
+    else ok = false;
+    if (!ok) return false;
+    if (am & (PRT_MAT_DIEL | PRT_MAT_ROUGH_DIEL)) {              // bxdf.cl:121-140
+        float eta = 1.0f;
+        if (t & (PRT_MAT_DIEL | PRT_MAT_ROUGH_DIEL)) eta = dielectric_eta(e, mat);
+        e.weight = e.weight * (eta * eta);
+    }
+    return true;
+}
+template <unsigned MATS>
+PT_DEV f3 bsdf_eval2(const DevScene& sc, const Event& e, const Mat& mat) {
+    const unsigned am = active_mats<MATS>(sc);
+    const unsigned t = mat.t & am;
+    f3 f;
+    if (t & PRT_MAT_DIFF) f = lambert_eval(e, mat);
+    else if (t & PRT_MAT_COND) f = conductor_eval(e, mat);
+    else if (t & PRT_MAT_ROUGH_COND) f = rough_conductor_eval(e.wi, e.wo, mat);
+    else if (t & PRT_MAT_DIEL) f = dielectric_eval(e, mat);
+    else if (t & PRT_MAT_ROUGH_DIEL) f = rough_dielectric_eval(e, mat);
+    else if (t & PRT_MAT_COAT) f = coat_eval(e, mat);
+    else f = splat(0.0f);
+    if (am & (PRT_MAT_DIEL | PRT_MAT_ROUGH_DIEL)) {              // bxdf.cl:204-223
+        float eta = 1.0f;
+        if (t & (PRT_MAT_DIEL | PRT_MAT_ROUGH_DIEL)) eta = dielectric_eta(e, mat);
+        f = f * (eta * eta);
+    }
+    return f;
+}
+template <unsigned MATS>
+PT_DEV float bsdf_pdf(const DevScene& sc, const Event& e, const Mat& mat) {
+    const unsigned t = mat.t & active_mats<MATS>(sc);
+    if (t & PRT_MAT_DIFF) return 0.0f;                           // LambertBSDF_pdf as compiled
+    else if (t & PRT_MAT_COND) return check_reflection(e.wi, e.wo) ? 1.0f : 0.0f;
+    else if (t & PRT_MAT_ROUGH_COND) return rough_conductor_pdf(e.wi, e.wo, mat);
+    else if (t & PRT_MAT_DIEL) return dielectric_pdf(e, mat);
+    else if (t & PRT_MAT_ROUGH_DIEL) return rough_dielectric_pdf(e, mat);
+    else if (t & PRT_MAT_COAT) return coat_pdf(e, mat);
+    return 0.0f;
+}
+
+// ---- phase functions + medium, kernels/phasefunctions/*.cl, kernels/media/homogeneous.cl:11-51 -------
+PT_DEV float hg(float g, float cosTheta) {
+    float term = 1.0f + g * g - 2.0f * g * cosTheta;
+    return PT_INV_FOUR_PI * (1.0f - g * g) / (term * prt_sqrt(term));
+}
+PT_DEV float phase_value(const DevScene& sc, f3 wi, f3 wo) {    // phase_eval (splat) == phase_pdf
+    if (sc.phase_function == 1) return hg(sc.phase_g, dot(wi, wo));
+    return PT_INV_FOUR_PI;
+}
+struct PhaseSample { f3 w, weight; float pdf; };
+PT_DEV void phase_sample(const DevScene& sc, f3 wi, PhaseSample& ps, Rng& rng) {
+    float xi_x = next1D(rng), xi_y = next1D(rng);
+    ps.weight = splat(1.0f);
+    if (sc.phase_function == 1 && sc.phase_g != 0.0f) {
+        const float g = sc.phase_g;
+        float phi = xi_x * PT_TWO_PI;
+        float q = (1.0f - g * g) / (1.0f + g * (xi_y * 2.0f - 1.0f));
+        float cosTheta = (1.0f + g * g - q * q) / (2.0f * g);
+        float sinTheta = prt_sqrt(prt_fmax(1.0f - cosTheta * cosTheta, 0.0f));
+        Frame tf = make_frame(wi);
+        ps.w = to_global(tf, F3(prt_cos(phi) * sinTheta, prt_sin(phi) * sinTheta, cosTheta));
+        ps.pdf = hg(g, cosTheta);
+    } else {
+        ps.w = uniform_sphere(xi_x, xi_y);
+        ps.pdf = PT_INV_FOUR_PI;
+    }
+}
+struct MediumSample { f3 p, weight; bool exited; };
+PT_DEV void medium_sample_distance(const DevScene& sc, MediumSample& ms, const Ray& ray, Rng& rng) {
+    const f3 sigmaT = splat(sc.fog_sigma_t), sigmaS = splat(sc.fog_sigma_s);
+    const float maxT = ray.t;
+    float mt;
+    if (sc.fog_abs_only) {
+        mt = maxT;
+        ms.weight = vexp(sigmaT * (-mt));
+        ms.exited = true;
+    } else {
+        // lane 3 of the float3 is the zero padding lane in the reference build
+        int lane = (int)prt_round(next1D(rng) * 3.0f);
+        float sigmaTc = (lane == 3) ? 0.0f : sc.fog_sigma_t;
+        float t = -prt_log(1.0f - next1D(rng)) / sigmaTc;
+        mt = prt_fmin(t, maxT);
+        ms.exited = (t >= maxT);
+        f3 tau = sigmaT * mt;
+        ms.weight = vexp(-tau);
+        float pdf;
+        if (ms.exited) {
+            pdf = avg3(vexp(-tau));
+        } else {
+            pdf = avg3(sigmaT * vexp(-tau));
+            ms.weight = ms.weight * sigmaS;
+        }
+        ms.weight = ms.weight / pdf;
+    }
+    ms.p = ray.origin + ray.dir * mt;
+}
+
+// ---- env map: kernels/utils.cl:46 + read_imagef(samplerA), OpenCL 1.2 s8.2, CLK_ADDRESS_CLAMP ----------
+PT_DEV f3 env_texel(const DevScene& sc, int i, int j) {
+    if (i < 0 || j < 0 || i >= sc.env_w || j >= sc.env_h) return splat(0.0f);
+    const float* p = sc.env + ((size_t)j * sc.env_w + i) * 3;
+    return F3(p[0], p[1], p[2]);
+}
+PT_DEV f3 env_lookup(const DevScene& sc, f3 dir) {
+    float cx = (prt_atan2(dir.z, dir.x) * PT_INV_TWO_PI) + 0.5f;
+    float cy = prt_acos(dir.y) * PT_INV_PI;
+    float u = cx * (float)sc.env_w, v = cy * (float)sc.env_h;
+    float fu = prt_floor(u - 0.5f), fv = prt_floor(v - 0.5f);
+    float a = (u - 0.5f) - fu, b = (v - 0.5f) - fv;
+    int i0 = (int)fu, j0 = (int)fv;
+    f3 t00 = env_texel(sc, i0, j0), t10 = env_texel(sc, i0 + 1, j0), t01 = env_texel(sc, i0, j0 + 1), t11 = env_texel(sc, i0 + 1, j0 + 1);
+    return t00 * ((1.f - a) * (1.f - b)) + t10 * (a * (1.f - b)) + t01 * ((1.f - a) * b) + t11 * (a * b);
+}
+
+PT_DEV float power_heuristic(float pdf0, float pdf1) { return (pdf0 * pdf0) / (pdf0 * pdf0 + pdf1 * pdf1); }
+
+// ---- per-pixel path state in registers ---------------------------------------------------------------------
+struct Path {
+    f3 origin, dir;
+    float time, dist;
+    f3 mask;
+    float acc[4];
+    unsigned total, samples;
+    unsigned diff, spec, trans, scatters;
+    bool wasSpecular, reset;
+};
+
+// ---- one segment: kernels/integrators/pathtracing.cl:4-120 + base.cl:31-260 -----------------------------
+// Adds the segment's radiance to path.acc and advances the path state.  MATS: compile-time
+// ACTIVE_MATS (0 = generic); MEDIUM: compile-time GLOBAL_MEDIUM.
+template <unsigned MATS, bool MEDIUM>
+PT_DEV void radiance_segment(const DevScene& sc, Ray& ray, Path& st, Rng& rng, unsigned* stack) {
+    const unsigned am = active_mats<MATS>(sc);
+    f3 emission = splat(0.0f);
+    float alpha = 1.0f;
+    int mesh_id;
+    const bool didHit = intersect_scene(sc, ray, mesh_id, stack);
+    const Mat mat = load_mat((mesh_id + 1) ? &sc.mats[mesh_id + 1] : &sc.mats[sc.n_meshes + 1]);
+    bool scattered = false;
+    bool done = false;
+    if (MEDIUM) {
+        MediumSample ms;
+        medium_sample_distance(sc, ms, ray, rng);
+        st.mask = st.mask * ms.weight;
+        if (!ms.exited && (int)st.scatters < sc.max_scattering_events) {
+            scattered = true;
+            ++st.scatters;
+            st.wasSpecular = false;
+            const float sig = sc.fog_sigma_t;
+            // volumeLightSample, base.cl:194-230 (samples the light from ray.pos, not ms.p: SURVEY §9-Q4)
+            f3 a = splat(0.0f);
+            {
+                LightSample rec;
+                if (sample_light0(sc, ray.pos, rec, rng)) {
+                    float fv = phase_value(sc, ray.dir, rec.d);
+                    f3 f = splat(fv);
+                    if (!(dot(f, f) == 0.0f)) {
+                        if (shadow(sc, ms.p, rec.d, rec.dist, stack)) {
+                            const Mat lm = load_mat(&sc.mats[sc.light_mesh + 1]);
+                            f3 tr = vexp(splat(sig) * (-1.0f * rec.dist));
+                            f3 contribution = tr * lm.color * f * power_heuristic(rec.pdf, fv);
+                            a = contribution / rec.pdf;
+                        }
+                    }
+                }
+            }
+            // volumePhaseSample, base.cl:232-260
+            f3 b = splat(0.0f);
+            PhaseSample ps;
+            phase_sample(sc, ray.dir, ps, rng);
+            {
+                Ray sRay;
+                sRay.origin = ms.p; sRay.dir = ps.w; sRay.normal = splat(0.0f); sRay.backside = false;
+                int mid;
+                if (intersect_scene(sc, sRay, mid, stack)) {
+                    const unsigned lbits = sc.mats[mid + 1].bits;
+                    if (lbits & PRT_MAT_LIGHT) {
+                        const Mat lm = load_mat(&sc.mats[mid + 1]);
+                        f3 tr = vexp(splat(sig) * (-1.0f * sRay.t));
+                        b = tr * lm.color * ps.weight * power_heuristic(ps.pdf, direct_pdf_mesh(sc, mid, sRay.dir, ms.p));
+                    }
+                }
+            }
+            emission = emission + (a + b) * st.mask;
+            ray.origin = ms.p;
+            ray.dir = ps.w;
+            st.mask = st.mask * ps.weight;
+        }
+    }
+    if (!scattered) {
+        if (!didHit) {
+            st.reset = true;
+            if (sc.alpha_testing) { emission = splat(0.0f); alpha = 0.0f; }
+            else emission = st.mask * env_lookup(sc, ray.dir);
+            done = true;
+        } else if ((am & PRT_MAT_LIGHT) && (mat.t & PRT_MAT_LIGHT)) {
+            if (st.wasSpecular) emission = emission + mat.color * st.mask;
+            st.reset = true;
+            done = true;
+        } else {
+            // makeLocalScatterEvent, base.cl:11-14
+            Event e;
+            e.frame = make_frame(ray.normal);
+            e.wi = to_local(e.frame, -ray.dir);
+            e.wo = splat(0.0f); e.weight = splat(1.0f); e.pdf = 1.0f; e.sampledLobe = 0;
+            bool terminate = false;
+            // handleSurface, base.cl:138-192
+            if ((am & PRT_MAT_LIGHT) && (mat.lobes & ~(PRT_LOBE_SPECULAR | PRT_LOBE_FORWARD) & 0xffu)) {
+                // bsdfSample, base.cl:31-77
+                f3 a = splat(0.0f);
+                if (!bsdf_sample2<MATS>(sc, e, ray, mat, rng)) {
+                    terminate = true;
+                } else {
+                    f3 wo = to_global(e.frame, e.wo);
+                    ray.origin = ray.pos;
+                    ray.dir = wo;
+                    int mid;
+                    if (intersect_scene(sc, ray, mid, stack)) {
+                        const unsigned lbits = sc.mats[mid + 1].bits;
+                        if (lbits & PRT_MAT_LIGHT) {
+                            const Mat lm = load_mat(&sc.mats[mid + 1]);
+                            a = lm.color * e.weight * power_heuristic(e.pdf, direct_pdf_mesh(sc, mid, ray.dir, ray.pos));
+                            if (MEDIUM) a = a * vexp(splat(sc.fog_sigma_t) * (-1.0f * ray.t));
+                        }
+                    }
+                }
+                // lightSample, base.cl:79-134 (from ray.pos = the probe ray's hit point: SURVEY §9-Q4)
+                f3 b = splat(0.0f);
+                LightSample rec;
+                if (sample_light0(sc, ray.pos, rec, rng)) {
+                    e.wo = to_local(e.frame, rec.d);
+                    f3 fr = bsdf_eval2<MATS>(sc, e, mat);
+                    if (!(dot(fr, fr) == 0.0f)) {
+                        if (shadow(sc, ray.pos, rec.d, rec.dist, stack)) {
+                            const Mat lm = load_mat(&sc.mats[sc.light_mesh + 1]);
+                            f3 contribution = lm.color * fr;
+                            if (MEDIUM) contribution = contribution * vexp(splat(sc.fog_sigma_t) * (-1.0f * rec.dist));
+                            contribution = contribution * power_heuristic(rec.pdf, bsdf_pdf<MATS>(sc, e, mat));
+                            b = contribution / rec.pdf;
+                        }
+                    }
+                }
+                emission = emission + (a + b) * st.mask;
+            } else {
+                if (!bsdf_sample2<MATS>(sc, e, ray, mat, rng)) {
+                    st.reset = true;
+                    done = true;
+                } else {
+                    ray.origin = ray.pos;
+                    ray.dir = to_global(e.frame, e.wo);
+                }
+            }
+            if (!done) {
+                st.wasSpecular = (e.sampledLobe & PRT_LOBE_SPECULAR) != 0;
+                st.mask = st.mask * e.weight;
+                st.diff += (e.sampledLobe & (PRT_LOBE_DIFFUSE_R | PRT_LOBE_GLOSSY_R)) != 0;
+                st.spec += (e.sampledLobe & PRT_LOBE_SPECULAR_R) != 0;
+                st.trans += (e.sampledLobe & PRT_LOBE_TRANSMISSIVE) != 0;
+                st.diff &= 0xffffu; st.spec &= 0xffffu; st.trans &= 0xffffu;   // ushort counters
+                if (terminate) {
+                    st.reset = true;
+                    done = true;
+                } else {
+                    st.scatters = 0;
+                    ++st.total;
+                }
+            }
+        }
+    }
+    if (!done) {
+        const float roulettePdf = fmax3(st.mask);                // pathtracing.cl:97-106
+        if (st.total > 2 && roulettePdf < 0.1f) {
+            if (next1D(rng) < roulettePdf) st.mask = st.mask / roulettePdf;
+            else { st.reset = true; done = true; }
+        }
+    }
+    if (!done) {
+        if (st.total >= (unsigned)sc.max_bounces || (int)st.diff >= sc.max_diff_bounces ||
+            (int)st.spec >= sc.max_spec_bounces || (int)st.trans >= sc.max_trans_bounces)
+            st.reset = true;                                     // pathtracing.cl:109-115
+    }
+    st.acc[0] += emission.x; st.acc[1] += emission.y; st.acc[2] += emission.z; st.acc[3] += alpha;
+}
+
+}  // namespace dev
+}  // namespace prt

@@ -1,0 +1,175 @@
+// pt_kernels.hip -- gfx950 kernels of libprt (see pt_device.h for the arithmetic contract).
+//
+//   render_kernel<MATS, MEDIUM>   the hot path: one lane = one pixel, n_frames segments per launch
+//   state_to_rtd / rtd_to_state   80 B/px SoA planes <-> the reference's 112 B RTD records
+//   count_kernel                  sum of samples / segments / frozen pixels (Msamples/s accounting)
+//
+// Launch geometry: 256-thread workgroups = 4 waves; each wave owns an 8x8 pixel tile (primary rays
+// of one wave walk the same BVH nodes), a workgroup a 16x16 tile.  A 1920x1080 frame is 8 160
+// workgroups >> 256 CUs.
+#include <hip/hip_runtime.h>
+
+#include "pt_device.h"
+#include "pt_launch.h"
+
+namespace prt {
+
+using namespace dev;
+
+template <unsigned MATS, bool MEDIUM>
+__global__ __launch_bounds__(256) void render_kernel(const DevScene sc, const DevCamera cam, const DevState S,
+                                                     const FrameArgs fa, float4* __restrict__ fb) {
+    // 16x16 workgroup tile, 8x8 per wave
+    const int tiles_x = (fa.width + 15) >> 4;
+    const int tile_x = (int)(blockIdx.x % (unsigned)tiles_x), tile_y = (int)(blockIdx.x / (unsigned)tiles_x);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lx = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int ly = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    if (lx >= fa.width || ly >= fa.rows) return;
+    const size_t id = (size_t)ly * (size_t)fa.width + (size_t)lx;
+    const int gx = lx, gy = ly + fa.row0;
+
+    Path st;
+    {
+        const float4 a = S.q0[id], b = S.q1[id], c = S.q2[id], d = S.q3[id];
+        const uint4 e = S.q4[id];
+        st.origin = F3(a.x, a.y, a.z); st.time = a.w;
+        st.dir = F3(b.x, b.y, b.z); st.dist = b.w;
+        st.mask = F3(c.x, c.y, c.z); st.total = prt_f2u(c.w);
+        st.acc[0] = d.x; st.acc[1] = d.y; st.acc[2] = d.z; st.acc[3] = d.w;
+        st.samples = e.x;
+        st.diff = e.y & 0xffffu; st.spec = e.y >> 16;
+        st.trans = e.z & 0xffffu; st.scatters = e.z >> 16;
+        st.wasSpecular = (e.w & 1u) != 0; st.reset = (e.w & 2u) != 0;
+    }
+    unsigned stack[PT_STACK_DEPTH];
+    bool ran = false;
+    for (unsigned f = 0; f < fa.n_frames; ++f) {
+        if (fa.spp_limit && st.reset && st.samples >= fa.spp_limit) break;     // frozen (the "N spp" rule)
+        const unsigned frame = fa.first_frame + f;
+        const int random0 = fa.seed_pairs[2 * f], random1 = fa.seed_pairs[2 * f + 1];
+        Rng rng;                                                               // kernels/main.cl:108-109
+        rng.s0 = (unsigned)gx * frame % 1000u + ((unsigned)random0 * 100u);
+        rng.s1 = (unsigned)gy * frame % 1000u + ((unsigned)random1 * 100u);
+        Ray ray;                                                               // tempToRay, main.cl:27
+        ray.origin = st.origin; ray.dir = st.dir;
+        ray.normal = splat(0.0f); ray.pos = splat(0.0f);
+        ray.t = st.dist; ray.backside = false; ray.time = st.time;
+        if (st.reset || st.samples == 0) {                                     // main.cl:122-136
+            ++st.samples;
+            st.total = 0; st.diff = 0; st.spec = 0; st.trans = 0; st.scatters = 0;
+            st.wasSpecular = true;
+            st.reset = false;
+            st.mask = splat(1.0f);
+            ray = create_cam_ray(gx, gy, fa.width, fa.full_height, cam, rng);
+        }
+        radiance_segment<MATS, MEDIUM>(sc, ray, st, rng, stack);               // main.cl:142
+        st.origin = ray.origin; st.dir = ray.dir;                              // rayToTemp, main.cl:28:
+        st.time = ray.t;                                                       //   {origin, dir, ray.t, ray.time}
+        st.dist = ray.time;                                                    //   -> {origin, dir, time, dist}
+        ran = true;
+    }
+    if (ran) {
+        S.q0[id] = make_float4(st.origin.x, st.origin.y, st.origin.z, st.time);
+        S.q1[id] = make_float4(st.dir.x, st.dir.y, st.dir.z, st.dist);
+        S.q2[id] = make_float4(st.mask.x, st.mask.y, st.mask.z, prt_u2f(st.total));
+        S.q3[id] = make_float4(st.acc[0], st.acc[1], st.acc[2], st.acc[3]);
+        S.q4[id] = make_uint4(st.samples, (st.diff & 0xffffu) | (st.spec << 16), (st.trans & 0xffffu) | (st.scatters << 16),
+                              (st.wasSpecular ? 1u : 0u) | (st.reset ? 2u : 0u));
+        const float ns = (float)st.samples;                                    // write_imagef, main.cl:159
+        fb[id] = make_float4(st.acc[0] / ns, st.acc[1] / ns, st.acc[2] / ns, st.acc[3] / ns);
+    }
+    if (fa.unfinished) {
+        const bool unfinished = !(fa.spp_limit && st.reset && st.samples >= fa.spp_limit);
+        const unsigned long long m = __ballot(unfinished);
+        if (m && lane == (int)__builtin_ctzll(__ballot(1))) atomicAdd(fa.unfinished, (unsigned long long)__popcll(m));
+    }
+}
+
+__global__ void state_to_rtd(const DevState S, prt_path_state* __restrict__ out, size_t n) {
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n) return;
+    const float4 a = S.q0[id], b = S.q1[id], c = S.q2[id], d = S.q3[id];
+    const uint4 e = S.q4[id];
+    prt_path_state r;
+    __builtin_memset(&r, 0, sizeof(r));
+    r.origin[0] = a.x; r.origin[1] = a.y; r.origin[2] = a.z; r.time = a.w;
+    r.dir[0] = b.x; r.dir[1] = b.y; r.dir[2] = b.z; r.dist = b.w;
+    r.mask[0] = c.x; r.mask[1] = c.y; r.mask[2] = c.z; r.total = prt_f2u(c.w);
+    r.acc[0] = d.x; r.acc[1] = d.y; r.acc[2] = d.z; r.acc[3] = d.w;
+    r.samples = e.x;
+    r.diff = (uint16_t)(e.y & 0xffffu); r.spec = (uint16_t)(e.y >> 16);
+    r.trans = (uint16_t)(e.z & 0xffffu); r.scatters = (uint16_t)(e.z >> 16);
+    r.was_specular = (uint8_t)(e.w & 1u); r.reset = (uint8_t)((e.w >> 1) & 1u);
+    out[id] = r;
+}
+
+__global__ void rtd_to_state(const prt_path_state* __restrict__ in, const DevState S, float4* __restrict__ fb, size_t n) {
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n) return;
+    const prt_path_state r = in[id];
+    S.q0[id] = make_float4(r.origin[0], r.origin[1], r.origin[2], r.time);
+    S.q1[id] = make_float4(r.dir[0], r.dir[1], r.dir[2], r.dist);
+    S.q2[id] = make_float4(r.mask[0], r.mask[1], r.mask[2], prt_u2f(r.total));
+    S.q3[id] = make_float4(r.acc[0], r.acc[1], r.acc[2], r.acc[3]);
+    S.q4[id] = make_uint4(r.samples, (uint32_t)r.diff | ((uint32_t)r.spec << 16), (uint32_t)r.trans | ((uint32_t)r.scatters << 16),
+                          (r.was_specular ? 1u : 0u) | (r.reset ? 2u : 0u));
+    if (r.samples) {
+        const float ns = (float)r.samples;
+        fb[id] = make_float4(r.acc[0] / ns, r.acc[1] / ns, r.acc[2] / ns, r.acc[3] / ns);
+    } else {
+        fb[id] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+// out[0] = sum samples, out[1] = sum acc.w (exact: acc.w is an integer-valued float < 2^24), out[2] = frozen pixels
+__global__ void count_kernel(const DevState S, size_t n, unsigned spp, unsigned long long* __restrict__ out) {
+    unsigned long long s = 0, g = 0, z = 0;
+    for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (size_t)gridDim.x * blockDim.x) {
+        const uint4 e = S.q4[id];
+        s += e.x;
+        g += (unsigned long long)S.q3[id].w;
+        z += (spp && (e.w & 2u) && e.x >= spp) ? 1u : 0u;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_down(s, off); g += __shfl_down(g, off); z += __shfl_down(z, off);
+    }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], s); atomicAdd(&out[1], g); atomicAdd(&out[2], z); }
+}
+
+// ---- host-side launchers -------------------------------------------------------------------------------
+template <unsigned MATS, bool MEDIUM>
+static void launch_variant(const DevScene& sc, const DevCamera& cam, const DevState& S, const FrameArgs& fa, float4* fb,
+                           hipStream_t stream) {
+    const unsigned tiles_x = (unsigned)((fa.width + 15) >> 4), tiles_y = (unsigned)((fa.rows + 15) >> 4);
+    hipLaunchKernelGGL((render_kernel<MATS, MEDIUM>), dim3(tiles_x * tiles_y), dim3(256), 0, stream, sc, cam, S, fa, fb);
+}
+
+const char* launch_render(const DevScene& sc, const DevCamera& cam, const DevState& S, const FrameArgs& fa, float4* fb,
+                          hipStream_t stream) {
+    constexpr unsigned LD = PRT_MAT_LIGHT | PRT_MAT_DIFF;
+    const unsigned am = sc.active_mats;
+    if (!sc.has_medium) {
+        if (am == LD) { launch_variant<LD, false>(sc, cam, S, fa, fb, stream); return "render_kernel<LIGHT|DIFF>"; }
+        launch_variant<0u, false>(sc, cam, S, fa, fb, stream);
+        return "render_kernel<generic>";
+    }
+    if (am == LD) { launch_variant<LD, true>(sc, cam, S, fa, fb, stream); return "render_kernel<LIGHT|DIFF,medium>"; }
+    launch_variant<0u, true>(sc, cam, S, fa, fb, stream);
+    return "render_kernel<generic,medium>";
+}
+
+void launch_state_to_rtd(const DevState& S, prt_path_state* out, size_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(state_to_rtd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, S, out, n);
+}
+void launch_rtd_to_state(const prt_path_state* in, const DevState& S, float4* fb, size_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(rtd_to_state, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, in, S, fb, n);
+}
+void launch_count(const DevState& S, size_t n, unsigned spp, unsigned long long* out3, hipStream_t stream) {
+    unsigned blocks = (unsigned)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(count_kernel, dim3(blocks), dim3(256), 0, stream, S, n, spp, out3);
+}
+
+}  // namespace prt

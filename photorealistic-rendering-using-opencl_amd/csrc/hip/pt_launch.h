@@ -1,0 +1,18 @@
+// pt_launch.h -- host-callable launchers of the kernels in pt_kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "prt_types.h"
+#include "pt_layout.h"
+
+namespace prt {
+
+// launches the scene-specialised variant (the AOT analogue of the reference's per-scene program
+// build, include/CL/cl_kernel.h); returns the variant's name for profiles/stats
+const char* launch_render(const DevScene& sc, const DevCamera& cam, const DevState& S, const FrameArgs& fa, float4* fb,
+                          hipStream_t stream);
+void launch_state_to_rtd(const DevState& S, prt_path_state* out, size_t n, hipStream_t stream);
+void launch_rtd_to_state(const prt_path_state* in, const DevState& S, float4* fb, size_t n, hipStream_t stream);
+void launch_count(const DevState& S, size_t n, unsigned spp, unsigned long long* out3, hipStream_t stream);
+
+}  // namespace prt

@@ -1,0 +1,98 @@
+// pt_layout.h -- how a scene and the per-pixel path state live in HBM on the MI355X side of the
+// prt C-ABI.  prt_upload_scene() re-packs the reference-layout host buffers (36-byte BVH nodes,
+// float4 vertex/normal soups behind a u64 index array, 256-byte Mesh records) into these
+// 16-byte-aligned records so that every device access is a dwordx4 load:
+//
+//   NodePair   64 B  one per INNER node: bounds of both children + what each child is.
+//              The reference walks `node -> children[first_child + {0,1}]` and tests both children
+//              per step (kernels/geometry/bvh.cl:144-196); storing the pair together turns two
+//              36-byte unaligned gathers into four aligned 16-byte loads.
+//   TriGeom    48 B  per leaf SLOT (triangles pre-gathered in primitive_indices order, so the
+//              u64 index indirection of kernels/geometry/triangle.cl:7 is gone): p0, e1 = p0-p1,
+//              e2 = p2-p0, n = cross(e1,e2) -- the exact float operations of triangle.cl:8-15 done
+//              once on the host (no contraction), hence identical bits.
+//   TriNrm     48 B  per slot: the three vertex normals, touched once per closest hit.
+//   prims      spheres 16 B, quads 80 B (with the ray-independent anchor and edge dot products
+//              of kernels/geometry/quad.cl:16,26-27 pre-computed by the same arithmetic).
+//   DevMaterial 48 B per mesh (+ guard at [0], OBJ material last).
+//
+// Path state: 5 float4 planes (SoA of 16-byte lanes), 80 B per pixel instead of the reference's
+// 112-byte AoS RTD; prt_read_state()/prt_write_state() convert to and from the RTD layout.
+#pragma once
+#include <stdint.h>
+
+namespace prt {
+
+struct alignas(16) NodePair {
+    // b0 = {c0.minx, c0.maxx, c0.miny, c0.maxy}, b1 = {c0.minz, c0.maxz, c1.minx, c1.maxx},
+    // b2 = {c1.miny, c1.maxy, c1.minz, c1.maxz}
+    float b[12];
+    // child k: meta[2k]   = inner: index of the child's NodePair; leaf: first slot
+    //          meta[2k+1] = inner: 0xFFFFFFFF;                    leaf: primitive count
+    uint32_t meta[4];
+};
+static_assert(sizeof(NodePair) == 64, "NodePair");
+
+struct alignas(16) TriGeom { float p0[3]; float e1[3]; float e2[3]; float n[3]; };
+struct alignas(16) TriNrm { float n0[4]; float n1[4]; float n2[4]; };
+static_assert(sizeof(TriGeom) == 48 && sizeof(TriNrm) == 48, "Tri records");
+
+struct alignas(16) DevSphere { float pos[3]; float radius; };
+struct alignas(16) DevQuad {
+    float base[3]; float area;
+    float edge0[3]; float e0e0;
+    float edge1[3]; float e1e1;
+    float normal[3]; float _p0;
+    float anchor[3]; float _p1;
+};
+struct alignas(16) DevMaterial {
+    float color[3]; float roughness;
+    float eta[3]; uint32_t bits;      // t | lobes << 16 | dist << 24
+    float k[3]; float _p;
+};
+static_assert(sizeof(DevSphere) == 16 && sizeof(DevQuad) == 80 && sizeof(DevMaterial) == 48, "prim records");
+
+// kernel argument block (passed by value: lives in the kernarg segment, read with scalar loads)
+struct DevScene {
+    const NodePair* pairs;
+    const TriGeom* tri_geom;
+    const TriNrm* tri_nrm;
+    const DevSphere* spheres;
+    const DevQuad* quads;
+    const DevMaterial* mats;        // [0] guard (zero), [1+i] mesh i, [1+n_meshes] OBJ material
+    const float* env;               // RGB float
+    int env_w, env_h;
+    uint32_t n_spheres, n_quads, quad_mesh_base, n_meshes;
+    uint32_t root_leaf_first, root_leaf_count;   // used when root_is_leaf
+    int root_is_leaf;
+    uint32_t light_sphere;          // LIGHT_INDICES[0] as index into spheres, or 0xFFFFFFFF
+    uint32_t light_quad;            // ... as index into quads, or 0xFFFFFFFF
+    uint32_t light_mesh;            // LIGHT_INDICES[0]
+    // prt_config
+    uint32_t active_mats, geom_flags;
+    int max_bounces, max_diff_bounces, max_spec_bounces, max_trans_bounces, max_scattering_events;
+    int has_medium, fog_abs_only, alpha_testing, phase_function;
+    float fog_sigma_s, fog_sigma_t, phase_g;
+    uint32_t ntrans_mask;
+};
+
+struct DevCamera { float position[4], view[4], up[4]; float fov[2]; float apertureRadius, focalDistance; };
+
+// path state planes
+struct DevState {
+    float4* q0;   // origin.xyz, time
+    float4* q1;   // dir.xyz, dist
+    float4* q2;   // mask.xyz, bits(total)
+    float4* q3;   // acc
+    uint4* q4;    // samples, diff | spec << 16, trans | scatters << 16, was_specular | reset << 1
+};
+
+struct FrameArgs {
+    int width, full_height, row0, rows;     // tile of the image
+    uint32_t first_frame, n_frames;
+    const int32_t* seed_pairs;              // device, 2 * n_frames
+    uint32_t spp_limit;
+    unsigned long long* unfinished;         // device counter: pixels not yet frozen (spp mode), or null
+};
+
+}  // namespace prt

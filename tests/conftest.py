@@ -1,0 +1,48 @@
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+PKG_NAME = "photorealistic-rendering-using-opencl_amd"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _build_once():
+    import __graft_entry__ as ge
+    ge.build()
+
+
+@pytest.fixture(scope="session")
+def prt():
+    """the product package (libprt.so built in-tree)"""
+    _build_once()
+    return importlib.import_module(PKG_NAME)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """the CPU checkers under oracle/ (test infrastructure)"""
+    _build_once()
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_api
+    return oracle_api
+
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+# scene variant -> (scene json, prt_phase, uses env map)
+VARIANTS = {
+    "cornell_coat": ("cornell_coat.json", 0, False),
+    "cornell_diffuse": ("cornell_diffuse.json", 0, False),
+    "cornell_roughcond": ("cornell_roughcond.json", 0, True),
+    "cornell_roughdiel": ("cornell_roughdiel.json", 0, True),
+    "cornell_media": ("cornell_media.json", 0, True),
+    "cornell_media_hg": ("cornell_media.json", 1, True),
+}

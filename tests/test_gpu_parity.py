@@ -1,0 +1,179 @@
+"""GPU parity tests: the HIP path behind the C ABI (libprt.so) against the CPU oracle
+(oracle/pt_oracle.c) and against the golden fixtures produced by the reference build.
+Bar: bit-identical path state (every field of the 112-byte RTD record) and framebuffer."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, VARIANTS
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(prt, variant, W, H, rows=None, row0=0):
+    scene_json, phase, use_env = VARIANTS[variant]
+    scene = prt.HostScene(scene_json)
+    cfg = scene.config()
+    cfg.phase_function = phase
+    cam = prt.default_camera(W, H)
+    env = prt.make_sky(64, 32) if use_env else None
+    r = prt.Renderer(cfg, device=0)
+    r.upload_scene(scene)
+    if env is not None:
+        r.upload_envmap(env)
+    r.set_camera(cam)
+    if rows is None:
+        r.resize(W, H)
+    else:
+        r.set_tile(W, H, row0, rows)
+    return scene, cfg, cam, env, r
+
+
+def _assert_same(oracle, ostate, oimg, state, img, what):
+    bad = oracle.state_fields_equal(ostate, state.view(oracle.PATH_STATE_DTYPE))
+    assert not bad, "%s: path state differs in %s" % (what, bad)
+    assert np.array_equal(np.ascontiguousarray(oimg).view(np.uint32), np.ascontiguousarray(img).view(np.uint32)), "%s: framebuffer differs" % what
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS))
+def test_hip_matches_golden(prt, oracle, variant):
+    g = np.load(os.path.join(GOLDEN, variant + ".npz"))
+    W, H, frames = int(g["width"]), int(g["height"]), int(g["frames"])
+    scene, cfg, cam, env, r = _setup(prt, variant, W, H)
+    r.render_frames(prt.seed_pairs(frames))
+    gstate = np.ascontiguousarray(g["state"]).view(oracle.PATH_STATE_DTYPE).reshape(-1)
+    _assert_same(oracle, gstate, g["image"], r.read_state(), r.read_framebuffer(), variant + " vs reference golden")
+    r.close()
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS))
+def test_hip_matches_oracle(prt, oracle, variant):
+    W, H, frames = 97, 61, 160          # ragged: not a multiple of the 16x16 workgroup tile
+    scene, cfg, cam, env, r = _setup(prt, variant, W, H)
+    seeds = prt.seed_pairs(frames)
+    r.render_frames(seeds)
+    ostate, oimg = oracle.Restatement().render(cfg, scene.desc, cam, W, H, seeds, env=env, threads=16)
+    _assert_same(oracle, ostate, oimg, r.read_state(), r.read_framebuffer(), variant)
+    st = r.counts()
+    assert st.samples == int(ostate["samples"].sum()) and st.segments == int(ostate["acc"][:, 3].sum())
+    r.close()
+
+
+def test_spp_mode_matches_golden_and_oracle(prt, oracle):
+    g = np.load(os.path.join(GOLDEN, "cornell_diffuse_spp.npz"))
+    W, H, maxf, spp = int(g["width"]), int(g["height"]), int(g["frames"]), int(g["spp"])
+    scene, cfg, cam, env, r = _setup(prt, "cornell_diffuse", W, H)
+    used = r.render_spp(spp, prt.seed_pairs(maxf))
+    assert used <= maxf
+    state, img = r.read_state(), r.read_framebuffer()
+    gstate = np.ascontiguousarray(g["state"]).view(oracle.PATH_STATE_DTYPE).reshape(-1)
+    _assert_same(oracle, gstate, g["image"], state, img, "spp golden")
+    assert (state["samples"] == spp).all() and (state["reset"] != 0).all()
+    st = r.counts(spp)
+    assert st.finished_pixels == W * H and st.samples == spp * W * H
+    r.close()
+
+
+def test_frame_batching_is_invisible(prt, oracle):
+    """frames 1..n in one call == the same frames in several calls (state carries over exactly)"""
+    W, H = 64, 40
+    scene, cfg, cam, env, r = _setup(prt, "cornell_coat", W, H)
+    seeds = prt.seed_pairs(70)
+    r.render_frames(seeds)
+    s1, i1 = r.read_state(), r.read_framebuffer()
+    r.reset()
+    r.render_frames(seeds[:2 * 33], first_frame=1)
+    r.render_frames(seeds[2 * 33:2 * 34], first_frame=34)
+    r.render_frames(seeds[2 * 34:], first_frame=35)
+    _assert_same(oracle, s1.view(oracle.PATH_STATE_DTYPE), i1, r.read_state(), r.read_framebuffer(), "batching")
+    r.close()
+
+
+def test_state_roundtrip_checkpoint(prt, oracle):
+    """prt_read_state / prt_write_state: resume from a downloaded checkpoint in a NEW context"""
+    W, H = 48, 32
+    scene, cfg, cam, env, r = _setup(prt, "cornell_roughcond", W, H)
+    seeds = prt.seed_pairs(60)
+    r.render_frames(seeds[:2 * 25])
+    ck = r.read_state()
+    r.render_frames(seeds[2 * 25:], first_frame=26)
+    s_full, i_full = r.read_state(), r.read_framebuffer()
+    r.close()
+    scene, cfg, cam, env, r2 = _setup(prt, "cornell_roughcond", W, H)
+    r2.write_state(ck)
+    r2.render_frames(seeds[2 * 25:], first_frame=26)
+    _assert_same(oracle, s_full.view(oracle.PATH_STATE_DTYPE), i_full, r2.read_state(), r2.read_framebuffer(), "checkpoint")
+    r2.close()
+
+
+def test_row_tiles_union_equals_full_frame(prt, oracle):
+    """multi-GPU partitioning: row tiles rendered by separate contexts == the full-frame render"""
+    W, H, frames = 80, 50, 64
+    scene, cfg, cam, env, r = _setup(prt, "cornell_diffuse", W, H)
+    seeds = prt.seed_pairs(frames)
+    r.render_frames(seeds)
+    full_img, full_state = r.read_framebuffer(), r.read_state()
+    r.close()
+    parts_i, parts_s = [], []
+    for row0, rows in ((0, 13), (13, 20), (33, 17)):
+        scene, cfg, cam, env, rt = _setup(prt, "cornell_diffuse", W, H, rows=rows, row0=row0)
+        rt.render_frames(seeds)
+        parts_i.append(rt.read_framebuffer())
+        parts_s.append(rt.read_state())
+        rt.close()
+    _assert_same(oracle, full_state.view(oracle.PATH_STATE_DTYPE), full_img,
+                 np.concatenate(parts_s), np.concatenate(parts_i, axis=0), "row tiles")
+
+
+def test_camera_change_and_reset(prt, oracle):
+    W, H = 56, 40
+    scene, cfg, cam, env, r = _setup(prt, "cornell_coat", W, H)
+    seeds = prt.seed_pairs(40)
+    r.render_frames(seeds)
+    cam2 = prt.orbit_camera(W, H, d_yaw=0.4, d_pitch=0.1, d_radius=-0.2)
+    r.set_camera(cam2)
+    r.reset()                                   # buffer_reset branch of render(), src/main.cpp:283-291
+    r.render_frames(seeds)
+    ostate, oimg = oracle.Restatement().render(cfg, scene.desc, cam2, W, H, seeds)
+    _assert_same(oracle, ostate, oimg, r.read_state(), r.read_framebuffer(), "orbit camera")
+    r.close()
+
+
+def test_empty_and_degenerate_inputs(prt, oracle):
+    # no OBJ at all: empty-leaf root; 1x1 image; zero frames
+    text = ('{"scene":{"spheres":[{"pos":[0,3,0],"radius":0.5,"material":{"color":[5,5,5],"type":0}}],'
+            '"quads":[{"vertices":[0,0,0,4,0,0,0,0,4],"material":{"color":[1,1,1]}}]}}')
+    scene = prt.HostScene(text, text=True)
+    cfg = scene.config()
+    for (W, H) in ((1, 1), (17, 3)):
+        cam = prt.default_camera(max(W, 2), max(H, 2))
+        r = prt.Renderer(cfg, device=0)
+        r.upload_scene(scene)
+        r.set_camera(cam)
+        r.resize(W, H)
+        r.render_frames(np.zeros(0, np.int32))
+        assert (r.read_state()["samples"] == 0).all()
+        seeds = prt.seed_pairs(30)
+        r.render_frames(seeds)
+        ostate, oimg = oracle.Restatement().render(cfg, scene.desc, cam, W, H, seeds)
+        _assert_same(oracle, ostate, oimg, r.read_state(), r.read_framebuffer(), "no-OBJ scene %dx%d" % (W, H))
+        r.close()
+
+
+def test_errors_are_reported_not_fatal(prt):
+    scene = prt.HostScene("cornell_diffuse.json")
+    cfg = scene.config()
+    r = prt.Renderer(cfg, device=0)
+    with pytest.raises(prt.PrtError):
+        r.render_frames(prt.seed_pairs(1))          # nothing uploaded yet
+    r.upload_scene(scene)
+    with pytest.raises(prt.PrtError):
+        r.resize(0, 10)
+    bad = prt.Config.from_buffer_copy(bytes(cfg))
+    bad.abi_version = 99
+    with pytest.raises(prt.PrtError):
+        prt.Renderer(bad, device=0)
+    with pytest.raises(prt.PrtError):
+        prt.Renderer(cfg, device=4096)
+    r.close()
