@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path (BASELINE.json):
+Msamples/s (width x height x spp / s) at 1920x1080 on scenes/cornell (Lambert + area light),
+1024 spp, plus the achieved algorithmic HBM GB/s of the render kernel against the gfx950 peak.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--spp S] [--width X --height Y]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A *step* is one complete render of the workload: reset, then frame-synchronous segments until
+every pixel has finished its S-th path (the reference's "N spp" in its own work accounting,
+SURVEY.md s8d).  Inputs (scene, BVH, camera, seed table) are resident in HBM before the timed
+region.  With N > 1 the frame is split into interleaved row blocks, one set per rank (pixels are
+independent; seeds use global pixel coordinates, so the union is bit-identical to the 1-GPU
+image), and ONE RCCL reduce(sum) of the zero-padded full-size framebuffer per step merges them on
+rank 0 -- inside the timed region.  Total work is fixed as N grows: "scaling": "strong".
+
+The JSON line also carries
+  roofline      the dominant kernel (render_kernel) priced in ALGORITHMIC bytes: 240 B per pixel
+                segment (112 B state read + 112 B state write + 16 B image write, what the
+                reference moves per work-item per launch) x segments executed, divided by the
+                kernel time measured live with HIP events on the launch stream (libprt does it
+                around its launches).  peak = 8 TB/s HBM3E.  `traffic` = measured HBM bytes per
+                launch from the rocprofv3 PMC passes committed under profiles/ (null if absent).
+  cpu_baseline  oracle/pt_oracle.c (a scalar-per-pixel CPU port, multi-threaded over pixels) on a
+                bounded sample of the same workload, rank 0, N = 1 only.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG_NAME = "photorealistic-rendering-using-opencl_amd"
+
+ALGO_BYTES_PER_SEGMENT = 240
+HBM_PEAK_GBPS = 8000.0                # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def interleaved_rows(height, world, rank, block=16):
+    """row indices of the rank's interleaved 16-row blocks (load balance: the teapot covers the
+    middle of the frame)"""
+    import numpy as np
+    rows = np.arange(height)
+    return rows[(rows // block) % world == rank]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp", type=int, default=1024)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--scene", default="cornell_diffuse.json")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
+        a.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libprt has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    prt = importlib.import_module(PKG_NAME)
+    import __graft_entry__ as ge
+    if not os.path.exists(os.path.join(ROOT, PKG_NAME, "libprt.so")):
+        ge.build()
+
+    W, H, spp = a.width, a.height, a.spp
+    scene = prt.HostScene(a.scene)
+    cfg = scene.config()
+    cam = prt.default_camera(W, H)
+    max_frames = max(64, spp * max(cfg.max_bounces, 8) + 64)      # a path has at most max_bounces (+1) segments
+    seeds = prt.seed_pairs(max_frames)
+
+    r = prt.Renderer(cfg, device=local_rank)
+    r.upload_scene(scene)
+    r.set_camera(cam)
+    stream = torch.cuda.current_stream()
+    r.set_stream(stream.cuda_stream)
+    if world == 1:
+        r.resize(W, H)
+        my_rows = None
+    else:
+        my_rows = interleaved_rows(H, world, rank)
+        r.set_row_blocks(W, H, 16, world, rank)
+        full = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+        tile = torch.zeros((len(my_rows), W, 4), dtype=torch.float32, device="cuda")
+        rows_t = torch.as_tensor(my_rows, device="cuda", dtype=torch.long)
+
+    kernel_ms = 0.0
+    launches = 0
+
+    def step(timed):
+        nonlocal kernel_ms, launches
+        r.reset()
+        r.render_spp(spp, seeds)
+        if world > 1:
+            r.copy_framebuffer_to_device(tile.data_ptr())
+            full.zero_()
+            full.index_copy_(0, rows_t, tile)
+            dist.reduce(full, dst=0, op=dist.ReduceOp.SUM)
+        if timed:
+            st = r.stats()
+            kernel_ms += st.kernel_ms
+            launches += st.launches
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step(False)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step(True)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    counts = r.counts(spp)
+    seg = torch.tensor([float(counts.segments), float(counts.samples), kernel_ms, float(launches)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        seg_sum = seg.clone()
+        dist.all_reduce(seg_sum, op=dist.ReduceOp.SUM)
+        seg_max = seg.clone()
+        dist.all_reduce(seg_max, op=dist.ReduceOp.MAX)
+        total_segments, total_samples = float(seg_sum[0]), float(seg_sum[1])
+        kernel_ms_max = float(seg_max[2])
+    else:
+        total_segments, total_samples = float(seg[0]), float(seg[1])
+        kernel_ms_max = kernel_ms
+
+    if rank == 0:
+        steps = max(a.steps, 1)
+        msamples = W * H * spp * steps / dt / 1e6
+        # rank-0 kernel: its own segments per step over its own kernel time
+        own_segments = float(counts.segments)
+        achieved = ALGO_BYTES_PER_SEGMENT * own_segments * steps / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("workload") == "%dx%d_%dspp_%s" % (W, H, spp, a.scene):
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Msamples/s (width x height x spp / s) at %dx%d" % (W, H),
+            "value": round(msamples, 3),
+            "unit": "Msamples/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "scenes/cornell (teapot DIFF = Lambert + sphere area light) %dx%d %dspp, %d x MI355X" % (W, H, spp, world),
+                       "scene": a.scene, "width": W, "height": H, "spp": spp,
+                       "mean_path_length": round(total_segments / max(total_samples, 1.0), 4),
+                       "segments_per_step": total_segments,
+                       "parallelism": "single GPU" if world == 1 else "interleaved 16-row blocks over %d ranks + 1 RCCL reduce" % world},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                         "kernel": "render_kernel", "algorithmic_bytes_per_segment": ALGO_BYTES_PER_SEGMENT,
+                         "launches": launches, "avg_launch_ms": round(kernel_ms / max(launches, 1), 4),
+                         "gsegments_per_s": round(own_segments * steps / (kernel_ms * 1e-3) / 1e9, 4) if kernel_ms > 0 else 0.0},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(prt, a.scene)
+        print(json.dumps(out))
+    r.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(prt, scene_json):
+    """oracle/pt_oracle.c timed on the host cores: 960x540 (1/2 of the frame in each dimension,
+    same camera) at 96 spp of the same scene -- about 10-30 s of CPU work on the GPU box."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_api as O
+    W, H, spp = 960, 540, 96
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 64))
+    scene = prt.HostScene(scene_json)
+    cfg = scene.config()
+    cam = prt.default_camera(W, H)
+    seeds = prt.seed_pairs(spp * max(cfg.max_bounces, 8) + 64)
+    rs = O.Restatement()
+    t0 = time.perf_counter()
+    state, _ = rs.render(cfg, scene.desc, cam, W, H, seeds, spp_limit=spp, threads=cores)
+    dt = time.perf_counter() - t0
+    assert (state["samples"] == spp).all()
+    return {"value": round(W * H * spp / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": "%dx%d %dspp of the same scene and camera (oracle/pt_oracle.c, %d threads, %.1f s)" % (W, H, spp, cores, dt),
+            "gsegments_per_s": round(float(state["acc"][:, 3].sum()) / dt / 1e9, 5)}
+
+
+if __name__ == "__main__":
+    main()

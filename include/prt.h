@@ -120,6 +120,11 @@ int prt_resize(prt_ctx* ctx, int width, int height);
  * a single-context render.  State/framebuffer calls then address the tile only.  Implies reset. */
 int prt_set_tile(prt_ctx* ctx, int width, int full_height, int row0, int rows);
 
+/* Interleaved variant for load balance: the frame is cut into blocks of `block_rows` rows and
+ * this context owns blocks part, part + n_parts, part + 2 n_parts, ... (local row order = global
+ * row order of the owned rows).  State/framebuffer calls address the owned rows only. */
+int prt_set_row_blocks(prt_ctx* ctx, int width, int full_height, int block_rows, int n_parts, int part);
+
 /* buffer_reset branch of render(), src/main.cpp:283-291: zero the path state. */
 int prt_reset(prt_ctx* ctx);
 

@@ -28,6 +28,20 @@ STATE_FIELDS = ["origin", "dir", "time", "dist", "mask", "acc", "total", "diff",
                 "was_specular", "reset", "samples"]
 
 
+def float_bits(x):
+    """bit patterns for exact comparison: -0 != +0, every NaN compares equal to every NaN (NaN
+    payload/sign propagation is the one thing IEEE 754 leaves to the implementation; it only
+    occurs in degenerate set-ups such as a 1-pixel-wide image, camera.cl:32 divides by W-1)"""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    b = x.view(np.uint32).copy()
+    b[np.isnan(x)] = 0x7FC00000
+    return b
+
+
+def images_equal(a, b):
+    return np.array_equal(float_bits(a), float_bits(b))
+
+
 def state_fields_equal(a, b):
     """bit-exact comparison of two RTD arrays, field by field (padding bytes and the unused w lanes
     of the float3 members are not state).  Returns the list of differing field names."""
@@ -36,9 +50,8 @@ def state_fields_equal(a, b):
         x, y = a[f], b[f]
         if f in ("origin", "dir", "mask"):
             x, y = x[..., :3], y[..., :3]
-        if x.dtype.kind == "f":      # compare bit patterns (NaN == NaN, -0 != +0)
-            x = np.ascontiguousarray(x).view(np.uint32)
-            y = np.ascontiguousarray(y).view(np.uint32)
+        if x.dtype.kind == "f":
+            x, y = float_bits(x), float_bits(y)
         if not np.array_equal(x, y):
             bad.append(f)
     return bad
@@ -115,6 +128,7 @@ class _Job(C.Structure):
     _fields_ = [("cfg", C.c_void_p), ("scene", C.c_void_p), ("camera", C.c_void_p),
                 ("env_rgb", C.c_void_p), ("env_w", C.c_int), ("env_h", C.c_int),
                 ("width", C.c_int), ("full_height", C.c_int), ("row0", C.c_int), ("rows", C.c_int),
+                ("block_rows", C.c_int), ("n_parts", C.c_int), ("part", C.c_int),
                 ("first_frame", C.c_uint32), ("n_frames", C.c_uint32), ("seed_pairs", C.c_void_p),
                 ("state", C.c_void_p), ("out_rgba", C.c_void_p), ("spp_limit", C.c_uint32), ("n_threads", C.c_int)]
 
@@ -137,7 +151,10 @@ class Restatement:
         self.last_diag = None
 
     def render(self, cfg, desc, camera, W, H, seed_pairs, first_frame=1, state=None, env=None,
-               spp_limit=0, threads=8, row0=0, rows=None):
+               spp_limit=0, threads=8, row0=0, rows=None, blocks=None):
+        """blocks = (block_rows, n_parts, part) selects interleaved row blocks (prt_set_row_blocks)"""
+        if blocks is not None:
+            rows = sum(1 for r in range(H) if (r // blocks[0]) % blocks[1] == blocks[2])
         rows = H if rows is None else rows
         n_frames = len(seed_pairs) // 2
         if state is None:
@@ -153,6 +170,7 @@ class Restatement:
             job.env_rgb = _ptr(env)
             job.env_h, job.env_w = env.shape[0], env.shape[1]
         job.width, job.full_height, job.row0, job.rows = W, H, row0, rows
+        job.block_rows, job.n_parts, job.part = blocks if blocks is not None else (1, 1, 0)
         job.first_frame, job.n_frames = first_frame, n_frames
         job.seed_pairs = _ptr(seeds)
         job.state = _ptr(state)

@@ -1166,7 +1166,9 @@ static void* worker_main(void* arg) {
     const pto_job* j = w->job;
     for (size_t id = w->lo; id < w->hi; ++id) {
         const int lx = (int)(id % (size_t)j->width), ly = (int)(id / (size_t)j->width);
-        const int gx = lx, gy = ly + j->row0;
+        const int gx = lx;
+        const int B = j->block_rows > 0 ? j->block_rows : 1, NP = j->n_parts > 0 ? j->n_parts : 1;
+        const int gy = j->row0 + (ly / B * NP + j->part) * B + ly % B;
         prt_path_state* st = &j->state[id];
         float* px = j->out_rgba + 4 * id;
         for (uint32_t f = 0; f < j->n_frames; ++f) {

@@ -11,7 +11,8 @@ typedef struct pto_job {
     const prt_scene_desc* scene;
     const prt_camera* camera;
     const float* env_rgb; int env_w, env_h;     /* NULL = 1x1 black */
-    int width, full_height, row0, rows;         /* tile = rows [row0,row0+rows) of width x full_height */
+    int width, full_height, row0, rows;         /* tile = `rows` local rows of width x full_height */
+    int block_rows, n_parts, part;              /* local row ly -> global row0 + (ly / B * n_parts + part) * B + ly % B (B = 0: contiguous) */
     uint32_t first_frame, n_frames;             /* frame numbers start at 1 */
     const int32_t* seed_pairs;                  /* 2*n_frames */
     prt_path_state* state;                      /* width*rows, in/out */

@@ -150,6 +150,11 @@ class Renderer:
         self._chk(self.lib.prt_set_tile(self.ctx, width, full_height, row0, rows), "prt_set_tile")
         self.width, self.height, self.rows = width, full_height, rows
 
+    def set_row_blocks(self, width, full_height, block_rows, n_parts, part):
+        self._chk(self.lib.prt_set_row_blocks(self.ctx, width, full_height, block_rows, n_parts, part), "prt_set_row_blocks")
+        rows = sum(1 for r in range(full_height) if (r // block_rows) % n_parts == part)
+        self.width, self.height, self.rows = width, full_height, rows
+
     def reset(self):
         self._chk(self.lib.prt_reset(self.ctx), "prt_reset")
 

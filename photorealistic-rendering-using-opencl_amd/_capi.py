@@ -77,6 +77,7 @@ PRT_API = [
     ("prt_upload_envmap", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     ("prt_resize", C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     ("prt_set_tile", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    ("prt_set_row_blocks", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     ("prt_reset", C.c_int, [C.c_void_p]),
     ("prt_render_frames", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     ("prt_render_spp", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]),

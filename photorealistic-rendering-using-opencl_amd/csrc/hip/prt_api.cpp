@@ -33,6 +33,7 @@ struct prt_ctx {
     DevCamera cam{};
     // frame
     int width = 0, full_height = 0, row0 = 0, rows = 0;
+    int block_rows = 1, n_parts = 1, part = 0;
     size_t npix = 0;
     DevState S{};
     float4* fb = nullptr;
@@ -305,10 +306,28 @@ extern "C" int prt_upload_envmap(prt_ctx* c, const float* rgb, int w, int h) {
     return PRT_OK;
 }
 
+static int alloc_frame(prt_ctx* c, int width, int full_height, int row0, int rows);
+
 extern "C" int prt_set_tile(prt_ctx* c, int width, int full_height, int row0, int rows) {
     CTX_CHECK(c);
     if (width <= 0 || full_height <= 0 || rows <= 0 || row0 < 0 || row0 + rows > full_height)
         return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_set_tile: bad tile");
+    c->block_rows = 1; c->n_parts = 1; c->part = 0;
+    return alloc_frame(c, width, full_height, row0, rows);
+}
+
+extern "C" int prt_set_row_blocks(prt_ctx* c, int width, int full_height, int block_rows, int n_parts, int part) {
+    CTX_CHECK(c);
+    if (width <= 0 || full_height <= 0 || block_rows <= 0 || n_parts <= 0 || part < 0 || part >= n_parts)
+        return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_set_row_blocks: bad arguments");
+    int rows = 0;
+    for (int r = 0; r < full_height; ++r) rows += ((r / block_rows) % n_parts == part);
+    if (rows == 0) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_set_row_blocks: this part owns no rows");
+    c->block_rows = block_rows; c->n_parts = n_parts; c->part = part;
+    return alloc_frame(c, width, full_height, 0, rows);
+}
+
+static int alloc_frame(prt_ctx* c, int width, int full_height, int row0, int rows) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     free_frame(c);
@@ -371,6 +390,7 @@ static int ready(prt_ctx* c, const char* who) {
 static FrameArgs frame_args(prt_ctx* c, uint32_t first_frame, uint32_t n, const int32_t* d_seeds, uint32_t spp, bool count) {
     FrameArgs fa;
     fa.width = c->width; fa.full_height = c->full_height; fa.row0 = c->row0; fa.rows = c->rows;
+    fa.block_rows = c->block_rows; fa.n_parts = c->n_parts; fa.part = c->part;
     fa.first_frame = first_frame; fa.n_frames = n; fa.seed_pairs = d_seeds; fa.spp_limit = spp;
     fa.unfinished = count ? c->d_counters : nullptr;
     return fa;

@@ -27,7 +27,8 @@ __global__ __launch_bounds__(256) void render_kernel(const DevScene sc, const De
     const int ly = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
     if (lx >= fa.width || ly >= fa.rows) return;
     const size_t id = (size_t)ly * (size_t)fa.width + (size_t)lx;
-    const int gx = lx, gy = ly + fa.row0;
+    const int gx = lx;
+    const int gy = fa.row0 + (ly / fa.block_rows * fa.n_parts + fa.part) * fa.block_rows + ly % fa.block_rows;
 
     Path st;
     {

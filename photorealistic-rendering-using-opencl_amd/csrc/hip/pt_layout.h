@@ -88,7 +88,8 @@ struct DevState {
 };
 
 struct FrameArgs {
-    int width, full_height, row0, rows;     // tile of the image
+    int width, full_height, row0, rows;     // tile of the image: `rows` local rows
+    int block_rows, n_parts, part;          // local row ly -> global row row0 + (ly / B * n_parts + part) * B + ly % B
     uint32_t first_frame, n_frames;
     const int32_t* seed_pairs;              // device, 2 * n_frames
     uint32_t spp_limit;

@@ -33,7 +33,7 @@ def _setup(prt, variant, W, H, rows=None, row0=0):
 def _assert_same(oracle, ostate, oimg, state, img, what):
     bad = oracle.state_fields_equal(ostate, state.view(oracle.PATH_STATE_DTYPE))
     assert not bad, "%s: path state differs in %s" % (what, bad)
-    assert np.array_equal(np.ascontiguousarray(oimg).view(np.uint32), np.ascontiguousarray(img).view(np.uint32)), "%s: framebuffer differs" % what
+    assert oracle.images_equal(oimg, img), "%s: framebuffer differs" % what
 
 
 @pytest.mark.parametrize("variant", list(VARIANTS))
@@ -124,6 +124,29 @@ def test_row_tiles_union_equals_full_frame(prt, oracle):
         rt.close()
     _assert_same(oracle, full_state.view(oracle.PATH_STATE_DTYPE), full_img,
                  np.concatenate(parts_s), np.concatenate(parts_i, axis=0), "row tiles")
+
+
+def test_interleaved_row_blocks_union_equals_full_frame(prt, oracle):
+    """the bench's multi-GPU split: interleaved 16-row blocks per rank"""
+    W, H, frames, parts = 64, 77, 48, 3
+    scene, cfg, cam, env, r = _setup(prt, "cornell_coat", W, H)
+    seeds = prt.seed_pairs(frames)
+    r.render_frames(seeds)
+    full_img, full_state = r.read_framebuffer(), r.read_state().reshape(H, W)
+    r.close()
+    got_img = np.zeros_like(full_img)
+    got_state = np.zeros_like(full_state)
+    for part in range(parts):
+        rows = np.array([y for y in range(H) if (y // 16) % parts == part])
+        rt = prt.Renderer(cfg, device=0)
+        rt.upload_scene(scene)
+        rt.set_camera(cam)
+        rt.set_row_blocks(W, H, 16, parts, part)
+        rt.render_frames(seeds)
+        got_img[rows] = rt.read_framebuffer()
+        got_state[rows] = rt.read_state().reshape(len(rows), W)
+        rt.close()
+    _assert_same(oracle, full_state.reshape(-1).view(oracle.PATH_STATE_DTYPE), full_img, got_state.reshape(-1), got_img, "row blocks")
 
 
 def test_camera_change_and_reset(prt, oracle):
