@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libprt.so")
+LIB_PATH = os.environ.get("PRT_LIB", os.path.join(HERE, "libprt.so"))   # PRT_LIB: A/B builds of the same product
 
 PRT_MAX_LIGHTS = 16
 PRT_ABI_VERSION = 1

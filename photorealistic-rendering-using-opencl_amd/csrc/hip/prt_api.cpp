@@ -185,19 +185,19 @@ extern "C" int prt_upload_scene(prt_ctx* c, const prt_scene_desc* s) {
         } else {
             sc.root_is_leaf = 0;
             std::vector<uint32_t> pair_of(N, 0xFFFFFFFFu);
-            std::vector<uint32_t> order;           // inner nodes in DFS pre-order
-            std::vector<uint32_t> st{0};
-            while (!st.empty()) {
-                uint32_t n = st.back(); st.pop_back();
-                if (n >= N) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: BVH child index out of range");
-                if (pair_of[n] != 0xFFFFFFFFu) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: BVH is not a tree");
-                pair_of[n] = (uint32_t)order.size();
-                order.push_back(n);
-                if (order.size() > N) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: BVH is not a tree");
+            std::vector<uint32_t> order;           // inner nodes in breadth-first order: top levels first (they go to LDS)
+            order.push_back(0);
+            pair_of[0] = 0;
+            for (size_t head = 0; head < order.size(); ++head) {
+                const uint32_t n = order[head];
                 const uint32_t fc = nodes[n].first_child_or_primitive;
                 if ((uint64_t)fc + 1 >= N) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: BVH child index out of range");
-                if (!nodes[fc + 1].is_leaf) st.push_back(fc + 1);
-                if (!nodes[fc].is_leaf) st.push_back(fc);
+                for (uint32_t ch = fc; ch <= fc + 1; ++ch) {
+                    if (nodes[ch].is_leaf) continue;
+                    if (pair_of[ch] != 0xFFFFFFFFu || order.size() >= N) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: BVH is not a tree");
+                    pair_of[ch] = (uint32_t)order.size();
+                    order.push_back(ch);
+                }
             }
             pairs.resize(order.size());
             for (size_t k = 0; k < order.size(); ++k) {
@@ -248,6 +248,7 @@ extern "C" int prt_upload_scene(prt_ctx* c, const prt_scene_desc* s) {
         return rc;
 
     sc.pairs = static_cast<const NodePair*>(c->d_pairs);
+    sc.n_pairs = (uint32_t)pairs.size();
     sc.tri_geom = static_cast<const TriGeom*>(c->d_tri_geom);
     sc.tri_nrm = static_cast<const TriNrm*>(c->d_tri_nrm);
     sc.spheres = static_cast<const DevSphere*>(c->d_spheres);

@@ -209,8 +209,30 @@ PT_DEV bool hit_triangle(const TriGeom* __restrict__ tg, unsigned slot, const Ra
 // the reference: both children's boxes are tested against the CURRENT ray.t before either leaf
 // is tested; leaf children are tested immediately, left first; of two inner children the nearer
 // (by entry distance, ties -> left) is followed and the other pushed.
-template <bool ANY_HIT>
-PT_DEV bool traverse(const DevScene& sc, const Ray& ray, float& best_t, TriHit& th, unsigned* stack) {
+// Slab test of both children of one NodePair against the ray (bvh.cl:11-26), `best_t` = ray->t.
+struct PairTest { float entry0, entry1; bool go0, go1; uint4 meta; };
+PT_DEV PairTest test_pair(const NodePair* __restrict__ pairs, unsigned node, const RayPre& p, float best_t) {
+    const float4* q = reinterpret_cast<const float4*>(pairs + node);
+    const float4 b0 = q[0], b1 = q[1], b2 = q[2];
+    PairTest r;
+    r.meta = *reinterpret_cast<const uint4*>(q + 3);
+    // child 0: x = b0.xy, y = b0.zw, z = b1.xy ; child 1: x = b1.zw, y = b2.xy, z = b2.zw
+    float e0x = prt_fma(p.nx ? b0.y : b0.x, p.ix, p.sx), x0x = prt_fma(p.nx ? b0.x : b0.y, p.ix, p.sx);
+    float e0y = prt_fma(p.ny ? b0.w : b0.z, p.iy, p.sy), x0y = prt_fma(p.ny ? b0.z : b0.w, p.iy, p.sy);
+    float e0z = prt_fma(p.nz ? b1.y : b1.x, p.iz, p.sz), x0z = prt_fma(p.nz ? b1.x : b1.y, p.iz, p.sz);
+    float e1x = prt_fma(p.nx ? b1.w : b1.z, p.ix, p.sx), x1x = prt_fma(p.nx ? b1.z : b1.w, p.ix, p.sx);
+    float e1y = prt_fma(p.ny ? b2.y : b2.x, p.iy, p.sy), x1y = prt_fma(p.ny ? b2.x : b2.y, p.iy, p.sy);
+    float e1z = prt_fma(p.nz ? b2.w : b2.z, p.iz, p.sz), x1z = prt_fma(p.nz ? b2.z : b2.w, p.iz, p.sz);
+    r.entry0 = hw_max(e0x, hw_max(e0y, hw_max(e0z, PT_EPS)));
+    const float exit0 = hw_min(x0x, hw_min(x0y, hw_min(x0z, best_t)));
+    r.entry1 = hw_max(e1x, hw_max(e1y, hw_max(e1z, PT_EPS)));
+    const float exit1 = hw_min(x1x, hw_min(x1y, hw_min(x1z, best_t)));
+    r.go0 = r.entry0 <= exit0;
+    r.go1 = r.entry1 <= exit1;
+    return r;
+}
+
+PT_DEV bool traverse(const DevScene& sc, const bool ANY_HIT, const Ray& ray, float& best_t, TriHit& th, unsigned* stack) {
     const RayPre p = ray_pre(ray);
     bool found = false;
     if (sc.root_is_leaf) {
@@ -222,21 +244,10 @@ PT_DEV bool traverse(const DevScene& sc, const Ray& ray, float& best_t, TriHit& 
     unsigned node = 0;
     int sp = 0;
     for (;;) {
-        const float4* q = reinterpret_cast<const float4*>(sc.pairs + node);
-        const float4 b0 = q[0], b1 = q[1], b2 = q[2];
-        const uint4 meta = *reinterpret_cast<const uint4*>(q + 3);
-        // child 0: x = b0.xy, y = b0.zw, z = b1.xy ; child 1: x = b1.zw, y = b2.xy, z = b2.zw
-        float e0x = prt_fma(p.nx ? b0.y : b0.x, p.ix, p.sx), x0x = prt_fma(p.nx ? b0.x : b0.y, p.ix, p.sx);
-        float e0y = prt_fma(p.ny ? b0.w : b0.z, p.iy, p.sy), x0y = prt_fma(p.ny ? b0.z : b0.w, p.iy, p.sy);
-        float e0z = prt_fma(p.nz ? b1.y : b1.x, p.iz, p.sz), x0z = prt_fma(p.nz ? b1.x : b1.y, p.iz, p.sz);
-        float e1x = prt_fma(p.nx ? b1.w : b1.z, p.ix, p.sx), x1x = prt_fma(p.nx ? b1.z : b1.w, p.ix, p.sx);
-        float e1y = prt_fma(p.ny ? b2.y : b2.x, p.iy, p.sy), x1y = prt_fma(p.ny ? b2.x : b2.y, p.iy, p.sy);
-        float e1z = prt_fma(p.nz ? b2.w : b2.z, p.iz, p.sz), x1z = prt_fma(p.nz ? b2.z : b2.w, p.iz, p.sz);
-        const float entry0 = hw_max(e0x, hw_max(e0y, hw_max(e0z, PT_EPS)));
-        const float exit0 = hw_min(x0x, hw_min(x0y, hw_min(x0z, best_t)));
-        const float entry1 = hw_max(e1x, hw_max(e1y, hw_max(e1z, PT_EPS)));
-        const float exit1 = hw_min(x1x, hw_min(x1y, hw_min(x1z, best_t)));
-        bool go0 = entry0 <= exit0, go1 = entry1 <= exit1;
+        const PairTest pt = test_pair(sc.pairs, node, p, best_t);
+        const uint4 meta = pt.meta;
+        const float entry0 = pt.entry0, entry1 = pt.entry1;
+        bool go0 = pt.go0, go1 = pt.go1;
         if (go0 && meta.y != 0xFFFFFFFFu) {                      // left child is a leaf
             for (unsigned i = meta.x; i < meta.x + meta.y; ++i)
                 if (hit_triangle(sc.tri_geom, i, ray, best_t, th)) { found = true; if (ANY_HIT) return true; }
@@ -296,17 +307,115 @@ PT_DEV bool hit_quad(const DevQuad& qd, const Ray& ray, float& best_t, f3& q_out
     return true;
 }
 
-// ---- intersect_scene, kernels/intersect.cl:158-236 -----------------------------------------------
-// in: ray.origin/dir/normal.  out: ray.t/normal/pos/backside, mesh_id (-1 = OBJ or nothing).
-PT_DEV bool intersect_scene(const DevScene& sc, Ray& ray, int& mesh_id, unsigned* stack) {
-    float t = PT_INF;
+// ---- workgroup-cooperative BVH traversal ------------------------------------------------------------
+// Measured on cornell at 1080p: a ray needs 2.9 node steps on average (most rays never enter the
+// teapot's boxes), yet nearly every wave contains a few rays that walk 30+ steps, so with one ray
+// per lane the whole wave pays the deepest walk (2.4 G segments/s with the teapot, 15 G without).
+// Therefore traversal is a WORKGROUP stage: every lane does the root step inline (bvh.cl:144-157
+// for node 0: the exact test the full walk starts with); rays that enter a child box are compacted
+// through LDS (ballot + one LDS atomic per wave) into dense waves, which walk them from the root
+// with the reference's exact visiting order and write the result back to the owner's LDS slot.
+// Two barriers per stage; three stages per path segment (closest, probe, shadow).
+struct TravReq { bool want, any; f3 o, d; float tmax; };
+struct TravRes { bool found; float t; TriHit th; };
+
+template <int BLOCK>
+struct WgShared {
+    float4 q0[BLOCK];        // queue: origin.xyz, tmax
+    float4 q1[BLOCK];        // queue: dir.xyz, bits(owner | any << 31)
+    float4 r0[BLOCK];        // result by owner: t, u, v, w
+    unsigned r1[BLOCK];      // result by owner: slot | found << 31
+    unsigned count[2];       // queue length, double-buffered by stage parity
+};
+
+// PT_COOPERATIVE = 0 (default): every lane walks its own ray (no LDS, no barriers).
+// PT_COOPERATIVE = 1: the workgroup-regrouped walk described above.  Measured on MI355X
+// (cornell_diffuse 1080p): regrouping removes ~6x of the traversal INSTRUCTIONS but the stage then
+// idles most waves at its two barriers while one or two waves walk a latency-bound chain, and the
+// register-limited occupancy (128 VGPRs -> 16 waves/CU) leaves nothing else to run: 1.7-2.0 G
+// segments/s against 2.4 G for the per-lane walk.  Kept as the starting point of the wavefront
+// split (a lean traversal kernel fed by compacted queues), see DESIGN.md.
+#ifndef PT_COOPERATIVE
+#define PT_COOPERATIVE 0
+#endif
+
+template <int BLOCK>
+PT_DEV TravRes wg_traverse(const DevScene& sc, WgShared<BLOCK>& sm, unsigned& parity, const TravReq& rq, unsigned* stack) {
+    TravRes res;
+    res.found = false; res.t = rq.tmax;
+    res.th.u = res.th.v = res.th.w = 0.0f; res.th.slot = 0;
+#if !PT_COOPERATIVE
+    (void)sm; (void)parity;
+    if (rq.want) {
+        Ray ray;
+        ray.origin = rq.o; ray.dir = rq.d;
+        res.found = traverse(sc, rq.any, ray, res.t, res.th, stack);
+    }
+    return res;
+#else
+    const unsigned lane = threadIdx.x & 63u;
+    bool deep = false;
+    if (rq.want) {
+        Ray ray;
+        ray.origin = rq.o; ray.dir = rq.d;
+        if (sc.root_is_leaf) {
+            res.found = traverse(sc, rq.any, ray, res.t, res.th, stack);      // tiny meshes: nothing to regroup
+        } else {
+            const PairTest pt = test_pair(sc.pairs, 0u, ray_pre(ray), rq.tmax);
+            deep = pt.go0 || pt.go1;     // otherwise the walk ends after its first step with nothing found
+        }
+    }
+    const unsigned long long m = __ballot(deep);
+    if (m) {
+        unsigned base = 0;
+        if (lane == (unsigned)__builtin_ctzll(m)) base = atomicAdd(&sm.count[parity], (unsigned)__popcll(m));
+        base = (unsigned)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(m));
+        if (deep) {
+            const unsigned idx = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+            sm.q0[idx] = make_float4(rq.o.x, rq.o.y, rq.o.z, rq.tmax);
+            sm.q1[idx] = make_float4(rq.d.x, rq.d.y, rq.d.z, prt_u2f(threadIdx.x | (rq.any ? 0x80000000u : 0u)));
+        }
+    }
+    __syncthreads();
+    const unsigned n = sm.count[parity];
+    if (threadIdx.x == 0) sm.count[parity ^ 1u] = 0;                          // for the next stage
+    for (unsigned base = (threadIdx.x & ~63u); base < n; base += BLOCK) {     // dense waves walk the queue
+        const unsigned i = base + lane;
+        if (i < n) {
+            const float4 a = sm.q0[i], b = sm.q1[i];
+            const unsigned ob = prt_f2u(b.w);
+            Ray ray;
+            ray.origin = F3(a.x, a.y, a.z); ray.dir = F3(b.x, b.y, b.z);
+            float t = a.w;
+            TriHit th;
+            th.u = th.v = th.w = 0.0f; th.slot = 0;
+            const bool found = traverse(sc, (ob >> 31) != 0, ray, t, th, stack);
+            const unsigned owner = ob & 0x7fffffffu;
+            sm.r0[owner] = make_float4(t, th.u, th.v, th.w);
+            sm.r1[owner] = th.slot | (found ? 0x80000000u : 0u);
+        }
+    }
+    __syncthreads();
+    if (deep) {
+        const float4 r = sm.r0[threadIdx.x];
+        const unsigned s1 = sm.r1[threadIdx.x];
+        res.found = (s1 >> 31) != 0;
+        res.t = r.x; res.th.u = r.y; res.th.v = r.z; res.th.w = r.w; res.th.slot = s1 & 0x7fffffffu;
+    }
+    parity ^= 1u;
+    return res;
+#endif
+}
+
+// ---- the rest of intersect_scene, kernels/intersect.cl:167-236, given the BVH result ----------------
+// in: ray.origin/dir/normal + traversal result.  out: ray.t/normal/pos/backside, mesh_id (-1 = OBJ or nothing).
+PT_DEV bool finish_closest(const DevScene& sc, Ray& ray, const TravRes& tr, int& mesh_id) {
+    float t = tr.t;
     mesh_id = -1;
-    TriHit th;
-    th.u = th.v = th.w = 0.0f; th.slot = 0;
-    if (traverse<false>(sc, ray, t, th, stack)) {
-        const float4* nq = reinterpret_cast<const float4*>(sc.tri_nrm + th.slot);
+    if (tr.found) {
+        const float4* nq = reinterpret_cast<const float4*>(sc.tri_nrm + tr.th.slot);
         const float4 a = nq[0], b = nq[1], c = nq[2];
-        ray.normal = F3(a.x, a.y, a.z) * th.w + F3(b.x, b.y, b.z) * th.u + F3(c.x, c.y, c.z) * th.v;
+        ray.normal = F3(a.x, a.y, a.z) * tr.th.w + F3(b.x, b.y, b.z) * tr.th.u + F3(c.x, c.y, c.z) * tr.th.v;   // triangle.cl:30-34
     }
     ray.normal = normalize(ray.normal);
     ray.pos = ray.origin + ray.dir * t;
@@ -339,13 +448,11 @@ PT_DEV bool intersect_scene(const DevScene& sc, Ray& ray, int& mesh_id, unsigned
     return t < PT_INF;
 }
 
-// ---- shadow, kernels/intersect.cl:94-152: true = unoccluded --------------------------------------
-PT_DEV bool shadow(const DevScene& sc, const f3 origin, const f3 dir, const float maxDist, unsigned* stack) {
+// ---- the rest of shadow(), kernels/intersect.cl:108-151, given that the BVH did not occlude: true = unoccluded
+PT_DEV bool finish_shadow(const DevScene& sc, const f3 origin, const f3 dir, const float maxDist) {
     Ray ray;
-    ray.origin = origin; ray.dir = dir; ray.t = maxDist;
+    ray.origin = origin; ray.dir = dir;
     float t = maxDist;
-    TriHit th;
-    if (traverse<true>(sc, ray, t, th, stack)) return false;
     if (sc.geom_flags & PRT_GEOM_SPHERE) {
         for (unsigned i = 0; i < sc.n_spheres; ++i)
             if (hit_sphere(sc.spheres[i], ray, t)) return false;     // an accepted hit always has t < maxDist
@@ -897,7 +1004,14 @@ PT_DEV f3 env_lookup(const DevScene& sc, f3 dir) {
 PT_DEV float power_heuristic(float pdf0, float pdf1) { return (pdf0 * pdf0) / (pdf0 * pdf0 + pdf1 * pdf1); }
 
 // ---- per-pixel path state in registers ---------------------------------------------------------------------
+// The closest hit of the ray a segment leaves behind.  The reference intersects that ray twice:
+// as the BSDF / phase probe of segment f (base.cl:57, :247) and again as the path ray of segment
+// f+1 (pathtracing.cl:27) -- same origin, same direction, same scene, hence the same result.
+// Inside one launch the second walk (BVH + spheres + quads) is skipped and this record is used.
+struct HitCache { bool valid, didHit, backside; float t; int mesh_id; f3 normal, pos; };
+
 struct Path {
+    HitCache hc;
     f3 origin, dir;
     float time, dist;
     f3 mask;
@@ -908,149 +1022,204 @@ struct Path {
 };
 
 // ---- one segment: kernels/integrators/pathtracing.cl:4-120 + base.cl:31-260 -----------------------------
-// Adds the segment's radiance to path.acc and advances the path state.  MATS: compile-time
-// ACTIVE_MATS (0 = generic); MEDIUM: compile-time GLOBAL_MEDIUM.
-template <unsigned MATS, bool MEDIUM>
-PT_DEV void radiance_segment(const DevScene& sc, Ray& ray, Path& st, Rng& rng, unsigned* stack) {
+// Every lane of the workgroup calls this in lock step (`live` = the lane has a pixel that is not
+// frozen); the three traversals of a segment are workgroup stages (wg_traverse), everything else
+// is per lane in the reference's order, so every RNG draw happens exactly where it does there.
+//   stage 1  closest hit of the path ray                                  (intersect_scene, pathtracing.cl:27)
+//   stage 2  surface: closest hit of the BSDF-sampled probe ray           (bsdfSample, base.cl:54-57)
+//            medium scatter: any-hit of the light shadow ray              (volumeLightSample, base.cl:219)
+//   stage 3  surface: any-hit of the light shadow ray                     (lightSample, base.cl:115)
+//            medium scatter: closest hit of the phase-sampled probe ray   (volumePhaseSample, base.cl:247)
+// MATS: compile-time ACTIVE_MATS (0 = generic); MEDIUM: compile-time GLOBAL_MEDIUM.
+template <unsigned MATS, bool MEDIUM, int BLOCK>
+PT_DEV void radiance_segment(const DevScene& sc, WgShared<BLOCK>& sm, unsigned& parity, const bool live,
+                             Ray& ray, Path& st, Rng& rng, unsigned* stack) {
     const unsigned am = active_mats<MATS>(sc);
     f3 emission = splat(0.0f);
     float alpha = 1.0f;
-    int mesh_id;
-    const bool didHit = intersect_scene(sc, ray, mesh_id, stack);
-    const Mat mat = load_mat((mesh_id + 1) ? &sc.mats[mesh_id + 1] : &sc.mats[sc.n_meshes + 1]);
-    bool scattered = false;
-    bool done = false;
-    if (MEDIUM) {
-        MediumSample ms;
-        medium_sample_distance(sc, ms, ray, rng);
-        st.mask = st.mask * ms.weight;
-        if (!ms.exited && (int)st.scatters < sc.max_scattering_events) {
-            scattered = true;
-            ++st.scatters;
-            st.wasSpecular = false;
-            const float sig = sc.fog_sigma_t;
-            // volumeLightSample, base.cl:194-230 (samples the light from ray.pos, not ms.p: SURVEY §9-Q4)
-            f3 a = splat(0.0f);
-            {
-                LightSample rec;
+    bool done = !live;
+
+    // ---------------- stage 1
+    const bool cached = live && st.hc.valid;
+    TravReq rq;
+    rq.want = live && !cached; rq.any = false; rq.o = ray.origin; rq.d = ray.dir; rq.tmax = PT_INF;
+    const TravRes r1 = wg_traverse<BLOCK>(sc, sm, parity, rq, stack);
+
+    int mesh_id = -1;
+    bool didHit = false;
+    Mat mat;
+    mat.color = mat.eta = mat.k = splat(0.0f); mat.roughness = 0.0f; mat.t = mat.lobes = mat.dist = 0;
+    enum { K_NONE = 0, K_SURFACE_MIS = 1, K_SCATTER = 2 };
+    int kind = K_NONE;
+    Event e;
+    e.wi = e.wo = splat(0.0f); e.weight = splat(1.0f); e.pdf = 1.0f; e.sampledLobe = 0;
+    e.frame.normal = e.frame.tangent = e.frame.bitangent = splat(0.0f);
+    bool terminate = false, surface = false;
+    MediumSample ms;
+    ms.p = splat(0.0f); ms.weight = splat(1.0f); ms.exited = true;
+    LightSample rec;
+    rec.d = splat(0.0f); rec.dist = 0.0f; rec.pdf = 1.0f;
+    float fv = 0.0f;                 // phase function value (scatter)
+    TravReq rq2;
+    rq2.want = false; rq2.any = false; rq2.o = rq2.d = splat(0.0f); rq2.tmax = PT_INF;
+
+    if (live) {
+        if (cached) {
+            didHit = st.hc.didHit; mesh_id = st.hc.mesh_id;
+            ray.t = st.hc.t; ray.normal = st.hc.normal; ray.pos = st.hc.pos; ray.backside = st.hc.backside;
+        } else {
+            didHit = finish_closest(sc, ray, r1, mesh_id);
+        }
+        st.hc.valid = false;
+        mat = load_mat((mesh_id + 1) ? &sc.mats[mesh_id + 1] : &sc.mats[sc.n_meshes + 1]);
+        bool scattered = false;
+        if (MEDIUM) {
+            medium_sample_distance(sc, ms, ray, rng);
+            st.mask = st.mask * ms.weight;
+            if (!ms.exited && (int)st.scatters < sc.max_scattering_events) {
+                scattered = true;
+                kind = K_SCATTER;
+                st.scatters = (st.scatters + 1u) & 0xffffu;
+                st.wasSpecular = false;
+                // volumeLightSample, base.cl:194-230 (samples the light from ray.pos, not ms.p: SURVEY s9-Q4)
                 if (sample_light0(sc, ray.pos, rec, rng)) {
-                    float fv = phase_value(sc, ray.dir, rec.d);
-                    f3 f = splat(fv);
-                    if (!(dot(f, f) == 0.0f)) {
-                        if (shadow(sc, ms.p, rec.d, rec.dist, stack)) {
-                            const Mat lm = load_mat(&sc.mats[sc.light_mesh + 1]);
-                            f3 tr = vexp(splat(sig) * (-1.0f * rec.dist));
-                            f3 contribution = tr * lm.color * f * power_heuristic(rec.pdf, fv);
-                            a = contribution / rec.pdf;
-                        }
+                    fv = phase_value(sc, ray.dir, rec.d);
+                    const f3 f = splat(fv);
+                    if (!(dot(f, f) == 0.0f)) { rq2.want = true; rq2.any = true; rq2.o = ms.p; rq2.d = rec.d; rq2.tmax = rec.dist; }
+                }
+            }
+        }
+        if (!scattered) {
+            if (!didHit) {
+                st.reset = true;
+                if (sc.alpha_testing) { emission = splat(0.0f); alpha = 0.0f; }
+                else emission = st.mask * env_lookup(sc, ray.dir);
+                done = true;
+            } else if ((am & PRT_MAT_LIGHT) && (mat.t & PRT_MAT_LIGHT)) {
+                if (st.wasSpecular) emission = emission + mat.color * st.mask;
+                st.reset = true;
+                done = true;
+            } else {
+                surface = true;
+                e.frame = make_frame(ray.normal);                       // makeLocalScatterEvent, base.cl:11-14
+                e.wi = to_local(e.frame, -ray.dir);
+                if ((am & PRT_MAT_LIGHT) && (mat.lobes & ~(PRT_LOBE_SPECULAR | PRT_LOBE_FORWARD) & 0xffu)) {
+                    kind = K_SURFACE_MIS;                               // handleSurface, base.cl:168-172
+                    if (!bsdf_sample2<MATS>(sc, e, ray, mat, rng)) {    // bsdfSample, base.cl:31-77
+                        terminate = true;
+                    } else {
+                        ray.origin = ray.pos;
+                        ray.dir = to_global(e.frame, e.wo);
+                        rq2.want = true; rq2.any = false; rq2.o = ray.origin; rq2.d = ray.dir; rq2.tmax = PT_INF;
+                    }
+                } else {
+                    if (!bsdf_sample2<MATS>(sc, e, ray, mat, rng)) {    // base.cl:175-181
+                        st.reset = true;
+                        done = true;
+                        surface = false;
+                    } else {
+                        ray.origin = ray.pos;
+                        ray.dir = to_global(e.frame, e.wo);
                     }
                 }
             }
-            // volumePhaseSample, base.cl:232-260
-            f3 b = splat(0.0f);
-            PhaseSample ps;
-            phase_sample(sc, ray.dir, ps, rng);
-            {
-                Ray sRay;
-                sRay.origin = ms.p; sRay.dir = ps.w; sRay.normal = splat(0.0f); sRay.backside = false;
-                int mid;
-                if (intersect_scene(sc, sRay, mid, stack)) {
-                    const unsigned lbits = sc.mats[mid + 1].bits;
-                    if (lbits & PRT_MAT_LIGHT) {
-                        const Mat lm = load_mat(&sc.mats[mid + 1]);
-                        f3 tr = vexp(splat(sig) * (-1.0f * sRay.t));
-                        b = tr * lm.color * ps.weight * power_heuristic(ps.pdf, direct_pdf_mesh(sc, mid, sRay.dir, ms.p));
-                    }
-                }
-            }
-            emission = emission + (a + b) * st.mask;
-            ray.origin = ms.p;
-            ray.dir = ps.w;
-            st.mask = st.mask * ps.weight;
         }
     }
-    if (!scattered) {
-        if (!didHit) {
-            st.reset = true;
-            if (sc.alpha_testing) { emission = splat(0.0f); alpha = 0.0f; }
-            else emission = st.mask * env_lookup(sc, ray.dir);
-            done = true;
-        } else if ((am & PRT_MAT_LIGHT) && (mat.t & PRT_MAT_LIGHT)) {
-            if (st.wasSpecular) emission = emission + mat.color * st.mask;
+
+    // ---------------- stage 2
+    const TravRes r2 = wg_traverse<BLOCK>(sc, sm, parity, rq2, stack);
+
+    f3 a = splat(0.0f), b = splat(0.0f);
+    PhaseSample ps;
+    ps.w = ps.weight = splat(0.0f); ps.pdf = 1.0f;
+    TravReq rq3;
+    rq3.want = false; rq3.any = false; rq3.o = rq3.d = splat(0.0f); rq3.tmax = PT_INF;
+    if (kind == K_SURFACE_MIS) {
+        if (rq2.want) {                                                  // the probe ray, base.cl:54-75
+            int mid;
+            const bool hit2 = finish_closest(sc, ray, r2, mid);
+            st.hc.valid = true; st.hc.didHit = hit2; st.hc.backside = ray.backside; st.hc.t = ray.t; st.hc.mesh_id = mid;
+            st.hc.normal = ray.normal; st.hc.pos = ray.pos;
+            if (hit2) {
+                const unsigned lbits = sc.mats[mid + 1].bits;
+                if (lbits & PRT_MAT_LIGHT) {
+                    const Mat lm = load_mat(&sc.mats[mid + 1]);
+                    a = lm.color * e.weight * power_heuristic(e.pdf, direct_pdf_mesh(sc, mid, ray.dir, ray.pos));
+                    if (MEDIUM) a = a * vexp(splat(sc.fog_sigma_t) * (-1.0f * ray.t));
+                }
+            }
+        }
+        // lightSample, base.cl:79-134 (from ray.pos = the probe ray's hit point: SURVEY s9-Q4)
+        if (sample_light0(sc, ray.pos, rec, rng)) {
+            e.wo = to_local(e.frame, rec.d);
+            const f3 fr = bsdf_eval2<MATS>(sc, e, mat);
+            if (!(dot(fr, fr) == 0.0f)) {
+                rq3.want = true; rq3.any = true; rq3.o = ray.pos; rq3.d = rec.d; rq3.tmax = rec.dist;
+                b = fr;                                                  // finished after stage 3
+            }
+        }
+    } else if (kind == K_SCATTER) {
+        if (rq2.want && !r2.found && finish_shadow(sc, rq2.o, rq2.d, rq2.tmax)) {   // base.cl:219-224
+            const Mat lm = load_mat(&sc.mats[sc.light_mesh + 1]);
+            const f3 tr = vexp(splat(sc.fog_sigma_t) * (-1.0f * rec.dist));
+            const f3 contribution = tr * lm.color * splat(fv) * power_heuristic(rec.pdf, fv);
+            a = contribution / rec.pdf;
+        }
+        phase_sample(sc, ray.dir, ps, rng);                              // volumePhaseSample, base.cl:232-260
+        rq3.want = true; rq3.any = false; rq3.o = ms.p; rq3.d = ps.w; rq3.tmax = PT_INF;
+    }
+
+    // ---------------- stage 3
+    const TravRes r3 = wg_traverse<BLOCK>(sc, sm, parity, rq3, stack);
+
+    if (kind == K_SURFACE_MIS) {
+        if (rq3.want && !r3.found && finish_shadow(sc, rq3.o, rq3.d, rq3.tmax)) {
+            const Mat lm = load_mat(&sc.mats[sc.light_mesh + 1]);
+            f3 contribution = lm.color * b;
+            if (MEDIUM) contribution = contribution * vexp(splat(sc.fog_sigma_t) * (-1.0f * rec.dist));
+            contribution = contribution * power_heuristic(rec.pdf, bsdf_pdf<MATS>(sc, e, mat));
+            b = contribution / rec.pdf;
+        } else {
+            b = splat(0.0f);
+        }
+        emission = emission + (a + b) * st.mask;
+    } else if (kind == K_SCATTER) {
+        Ray sRay;
+        sRay.origin = ms.p; sRay.dir = ps.w; sRay.normal = splat(0.0f); sRay.pos = splat(0.0f); sRay.backside = false;
+        sRay.t = PT_INF; sRay.time = 0.0f;
+        int mid;
+        const bool hit3 = finish_closest(sc, sRay, r3, mid);
+        st.hc.valid = true; st.hc.didHit = hit3; st.hc.backside = sRay.backside; st.hc.t = sRay.t; st.hc.mesh_id = mid;
+        st.hc.normal = sRay.normal; st.hc.pos = sRay.pos;
+        if (hit3) {
+            const unsigned lbits = sc.mats[mid + 1].bits;
+            if (lbits & PRT_MAT_LIGHT) {
+                const Mat lm = load_mat(&sc.mats[mid + 1]);
+                const f3 tr = vexp(splat(sc.fog_sigma_t) * (-1.0f * sRay.t));
+                b = tr * lm.color * ps.weight * power_heuristic(ps.pdf, direct_pdf_mesh(sc, mid, sRay.dir, ms.p));
+            }
+        }
+        emission = emission + (a + b) * st.mask;
+        ray.origin = ms.p;                                               // pathtracing.cl:58-61
+        ray.dir = ps.w;
+        st.mask = st.mask * ps.weight;
+    }
+    if (surface && !done) {                                              // handleSurface tail, base.cl:183-191
+        st.wasSpecular = (e.sampledLobe & PRT_LOBE_SPECULAR) != 0;
+        st.mask = st.mask * e.weight;
+        st.diff = (st.diff + ((e.sampledLobe & (PRT_LOBE_DIFFUSE_R | PRT_LOBE_GLOSSY_R)) != 0)) & 0xffffu;
+        st.spec = (st.spec + ((e.sampledLobe & PRT_LOBE_SPECULAR_R) != 0)) & 0xffffu;
+        st.trans = (st.trans + ((e.sampledLobe & PRT_LOBE_TRANSMISSIVE) != 0)) & 0xffffu;
+        if (terminate) {
             st.reset = true;
             done = true;
         } else {
-            // makeLocalScatterEvent, base.cl:11-14
-            Event e;
-            e.frame = make_frame(ray.normal);
-            e.wi = to_local(e.frame, -ray.dir);
-            e.wo = splat(0.0f); e.weight = splat(1.0f); e.pdf = 1.0f; e.sampledLobe = 0;
-            bool terminate = false;
-            // handleSurface, base.cl:138-192
-            if ((am & PRT_MAT_LIGHT) && (mat.lobes & ~(PRT_LOBE_SPECULAR | PRT_LOBE_FORWARD) & 0xffu)) {
-                // bsdfSample, base.cl:31-77
-                f3 a = splat(0.0f);
-                if (!bsdf_sample2<MATS>(sc, e, ray, mat, rng)) {
-                    terminate = true;
-                } else {
-                    f3 wo = to_global(e.frame, e.wo);
-                    ray.origin = ray.pos;
-                    ray.dir = wo;
-                    int mid;
-                    if (intersect_scene(sc, ray, mid, stack)) {
-                        const unsigned lbits = sc.mats[mid + 1].bits;
-                        if (lbits & PRT_MAT_LIGHT) {
-                            const Mat lm = load_mat(&sc.mats[mid + 1]);
-                            a = lm.color * e.weight * power_heuristic(e.pdf, direct_pdf_mesh(sc, mid, ray.dir, ray.pos));
-                            if (MEDIUM) a = a * vexp(splat(sc.fog_sigma_t) * (-1.0f * ray.t));
-                        }
-                    }
-                }
-                // lightSample, base.cl:79-134 (from ray.pos = the probe ray's hit point: SURVEY §9-Q4)
-                f3 b = splat(0.0f);
-                LightSample rec;
-                if (sample_light0(sc, ray.pos, rec, rng)) {
-                    e.wo = to_local(e.frame, rec.d);
-                    f3 fr = bsdf_eval2<MATS>(sc, e, mat);
-                    if (!(dot(fr, fr) == 0.0f)) {
-                        if (shadow(sc, ray.pos, rec.d, rec.dist, stack)) {
-                            const Mat lm = load_mat(&sc.mats[sc.light_mesh + 1]);
-                            f3 contribution = lm.color * fr;
-                            if (MEDIUM) contribution = contribution * vexp(splat(sc.fog_sigma_t) * (-1.0f * rec.dist));
-                            contribution = contribution * power_heuristic(rec.pdf, bsdf_pdf<MATS>(sc, e, mat));
-                            b = contribution / rec.pdf;
-                        }
-                    }
-                }
-                emission = emission + (a + b) * st.mask;
-            } else {
-                if (!bsdf_sample2<MATS>(sc, e, ray, mat, rng)) {
-                    st.reset = true;
-                    done = true;
-                } else {
-                    ray.origin = ray.pos;
-                    ray.dir = to_global(e.frame, e.wo);
-                }
-            }
-            if (!done) {
-                st.wasSpecular = (e.sampledLobe & PRT_LOBE_SPECULAR) != 0;
-                st.mask = st.mask * e.weight;
-                st.diff += (e.sampledLobe & (PRT_LOBE_DIFFUSE_R | PRT_LOBE_GLOSSY_R)) != 0;
-                st.spec += (e.sampledLobe & PRT_LOBE_SPECULAR_R) != 0;
-                st.trans += (e.sampledLobe & PRT_LOBE_TRANSMISSIVE) != 0;
-                st.diff &= 0xffffu; st.spec &= 0xffffu; st.trans &= 0xffffu;   // ushort counters
-                if (terminate) {
-                    st.reset = true;
-                    done = true;
-                } else {
-                    st.scatters = 0;
-                    ++st.total;
-                }
-            }
+            st.scatters = 0;                                             // pathtracing.cl:93-94
+            ++st.total;
         }
     }
     if (!done) {
-        const float roulettePdf = fmax3(st.mask);                // pathtracing.cl:97-106
+        const float roulettePdf = fmax3(st.mask);                        // pathtracing.cl:97-106
         if (st.total > 2 && roulettePdf < 0.1f) {
             if (next1D(rng) < roulettePdf) st.mask = st.mask / roulettePdf;
             else { st.reset = true; done = true; }
@@ -1059,9 +1228,9 @@ PT_DEV void radiance_segment(const DevScene& sc, Ray& ray, Path& st, Rng& rng, u
     if (!done) {
         if (st.total >= (unsigned)sc.max_bounces || (int)st.diff >= sc.max_diff_bounces ||
             (int)st.spec >= sc.max_spec_bounces || (int)st.trans >= sc.max_trans_bounces)
-            st.reset = true;                                     // pathtracing.cl:109-115
+            st.reset = true;                                             // pathtracing.cl:109-115
     }
-    st.acc[0] += emission.x; st.acc[1] += emission.y; st.acc[2] += emission.z; st.acc[3] += alpha;
+    if (live) { st.acc[0] += emission.x; st.acc[1] += emission.y; st.acc[2] += emission.z; st.acc[3] += alpha; }
 }
 
 }  // namespace dev

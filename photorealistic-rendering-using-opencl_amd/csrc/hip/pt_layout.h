@@ -54,7 +54,8 @@ static_assert(sizeof(DevSphere) == 16 && sizeof(DevQuad) == 80 && sizeof(DevMate
 
 // kernel argument block (passed by value: lives in the kernarg segment, read with scalar loads)
 struct DevScene {
-    const NodePair* pairs;
+    const NodePair* pairs;          // breadth-first order
+    uint32_t n_pairs;
     const TriGeom* tri_geom;
     const TriNrm* tri_nrm;
     const DevSphere* spheres;
