@@ -39,14 +39,6 @@ ALGO_BYTES_PER_SEGMENT = 240
 HBM_PEAK_GBPS = 8000.0                # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def interleaved_rows(height, world, rank, block=16):
-    """row indices of the rank's interleaved 16-row blocks (load balance: the teapot covers the
-    middle of the frame)"""
-    import numpy as np
-    rows = np.arange(height)
-    return rows[(rows // block) % world == rank]
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -78,6 +70,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     prt = importlib.import_module(PKG_NAME)
+    par = importlib.import_module(PKG_NAME + ".parallel")
     import __graft_entry__ as ge
     if not os.path.exists(os.path.join(ROOT, PKG_NAME, "libprt.so")):
         ge.build()
@@ -98,11 +91,9 @@ def main():
         r.resize(W, H)
         my_rows = None
     else:
-        my_rows = interleaved_rows(H, world, rank)
-        r.set_row_blocks(W, H, 16, world, rank)
-        full = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+        my_rows = par.rows_of_rank(H, world, rank)
+        r.set_row_blocks(W, H, par.BLOCK_ROWS, world, rank)
         tile = torch.zeros((len(my_rows), W, 4), dtype=torch.float32, device="cuda")
-        rows_t = torch.as_tensor(my_rows, device="cuda", dtype=torch.long)
 
     kernel_ms = 0.0
     launches = 0
@@ -113,9 +104,7 @@ def main():
         r.render_spp(spp, seeds)
         if world > 1:
             r.copy_framebuffer_to_device(tile.data_ptr())
-            full.zero_()
-            full.index_copy_(0, rows_t, tile)
-            dist.reduce(full, dst=0, op=dist.ReduceOp.SUM)
+            par.merge_on_rank0(tile, my_rows, H, W, dist)
         if timed:
             st = r.stats()
             kernel_ms += st.kernel_ms

@@ -159,6 +159,12 @@ int prt_get_stats(prt_ctx* ctx, prt_stats* stats);
 /* device-side reduction of samples / segments / frozen pixels (fills those prt_stats fields) */
 int prt_query_counts(prt_ctx* ctx, uint32_t spp, prt_stats* stats);
 
+/* Diagnostics: evaluates one function of include/prt_detmath.h ON THE DEVICE for n inputs
+ * (fn: 0 sin, 1 cos, 2 tan, 3 exp, 4 log, 5 acos, 6 atan2(a,b), 7 pow(a,b), 8 sqrt, 9 a/b,
+ * 10 fma(a,b,a), 11 fmin(a,b), 12 fmax(a,b), 13 round, 14 floor, 15 1/a).  Host arrays in and out.
+ * The numerics contract says the result must equal the host evaluation bit for bit. */
+int prt_selftest_math(prt_ctx* ctx, int fn, const float* a, const float* b, float* out, int n);
+
 const char* prt_last_error(prt_ctx* ctx);
 /* message for a failed prt_create (ctx == NULL) */
 const char* prt_last_global_error(void);

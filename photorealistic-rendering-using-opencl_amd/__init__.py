@@ -204,6 +204,14 @@ class Renderer:
         self._chk(self.lib.prt_query_counts(self.ctx, spp, C.byref(st)), "prt_query_counts")
         return st
 
+    def selftest_math(self, fn, a, b):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        b = np.ascontiguousarray(b, dtype=np.float32)
+        out = np.zeros_like(a)
+        self._chk(self.lib.prt_selftest_math(self.ctx, fn, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p),
+                                             out.ctypes.data_as(C.c_void_p), a.size), "prt_selftest_math")
+        return out
+
     def close(self):
         if getattr(self, "ctx", None) and self.ctx.value:
             self.lib.prt_destroy(self.ctx)

@@ -537,3 +537,23 @@ extern "C" int prt_query_counts(prt_ctx* c, uint32_t spp, prt_stats* out) {
     *out = c->stats;
     return PRT_OK;
 }
+
+extern "C" int prt_selftest_math(prt_ctx* c, int fn, const float* a, const float* b, float* out, int n) {
+    CTX_CHECK(c);
+    if (!a || !b || !out || n <= 0) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_selftest_math: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    float *da = nullptr, *db = nullptr, *dout = nullptr;
+    const size_t bytes = (size_t)n * sizeof(float);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&da), bytes);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&db), bytes);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&dout), bytes);
+    if (e == hipSuccess) e = hipMemcpy(da, a, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(db, b, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) { launch_selftest_math(fn, da, db, dout, n, c->stream); e = hipStreamSynchronize(c->stream); }
+    if (e == hipSuccess) e = hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost);
+    if (da) (void)hipFree(da);
+    if (db) (void)hipFree(db);
+    if (dout) (void)hipFree(dout);
+    HIPCHK(c, e);
+    return PRT_OK;
+}

@@ -165,6 +165,33 @@ __global__ void count_kernel(const DevState S, size_t n, unsigned spp, unsigned 
     if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], s); atomicAdd(&out[1], g); atomicAdd(&out[2], z); }
 }
 
+// the same switch is evaluated on the host by oracle/detmath_probe.c
+__global__ void selftest_math_kernel(int fn, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int n) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    const float x = a[i], y = b[i];
+    float r;
+    switch (fn) {
+        case 0: r = prt_sin(x); break;
+        case 1: r = prt_cos(x); break;
+        case 2: r = prt_tan(x); break;
+        case 3: r = prt_exp(x); break;
+        case 4: r = prt_log(x); break;
+        case 5: r = prt_acos(x); break;
+        case 6: r = prt_atan2(x, y); break;
+        case 7: r = prt_pow(x, y); break;
+        case 8: r = prt_sqrt(x); break;
+        case 9: r = x / y; break;
+        case 10: r = prt_fma(x, y, x); break;
+        case 11: r = prt_fmin(x, y); break;
+        case 12: r = prt_fmax(x, y); break;
+        case 13: r = prt_round(x); break;
+        case 14: r = prt_floor(x); break;
+        default: r = prt_recip(x); break;
+    }
+    out[i] = r;
+}
+
 // ---- host-side launchers -------------------------------------------------------------------------------
 template <unsigned MATS, bool MEDIUM>
 static void launch_variant(const DevScene& sc, const DevCamera& cam, const DevState& S, const FrameArgs& fa, float4* fb,
@@ -193,6 +220,9 @@ void launch_state_to_rtd(const DevState& S, prt_path_state* out, size_t n, hipSt
 }
 void launch_rtd_to_state(const prt_path_state* in, const DevState& S, float4* fb, size_t n, hipStream_t stream) {
     hipLaunchKernelGGL(rtd_to_state, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, in, S, fb, n);
+}
+void launch_selftest_math(int fn, const float* a, const float* b, float* out, int n, hipStream_t stream) {
+    hipLaunchKernelGGL(selftest_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, fn, a, b, out, n);
 }
 void launch_count(const DevState& S, size_t n, unsigned spp, unsigned long long* out3, hipStream_t stream) {
     unsigned blocks = (unsigned)((n + 255) / 256);

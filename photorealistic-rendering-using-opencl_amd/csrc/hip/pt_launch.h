@@ -13,6 +13,7 @@ const char* launch_render(const DevScene& sc, const DevCamera& cam, const DevSta
                           hipStream_t stream);
 void launch_state_to_rtd(const DevState& S, prt_path_state* out, size_t n, hipStream_t stream);
 void launch_rtd_to_state(const prt_path_state* in, const DevState& S, float4* fb, size_t n, hipStream_t stream);
+void launch_selftest_math(int fn, const float* a, const float* b, float* out, int n, hipStream_t stream);
 void launch_count(const DevState& S, size_t n, unsigned spp, unsigned long long* out3, hipStream_t stream);
 
 }  // namespace prt
