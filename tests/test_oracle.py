@@ -1,0 +1,91 @@
+"""The CPU oracle (oracle/pt_oracle.c) against the golden fixtures produced by the reference
+build, against the reference build itself where it is present (development container), and
+through size-independent properties."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, VARIANTS
+
+
+def setup(prt, variant, W, H):
+    scene_json, phase, use_env = VARIANTS[variant]
+    scene = prt.HostScene(scene_json)
+    cfg = scene.config()
+    cfg.phase_function = phase
+    return scene, cfg, prt.default_camera(W, H), (prt.make_sky(64, 32) if use_env else None)
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS) + ["cornell_diffuse_spp"])
+def test_oracle_reproduces_reference_golden(prt, oracle, variant):
+    g = np.load(os.path.join(GOLDEN, variant + ".npz"))
+    W, H, frames, spp = int(g["width"]), int(g["height"]), int(g["frames"]), int(g["spp"])
+    scene, cfg, cam, env = setup(prt, variant.replace("_spp", ""), W, H)
+    state, img = oracle.Restatement().render(cfg, scene.desc, cam, W, H, prt.seed_pairs(frames), env=env, spp_limit=spp, threads=4)
+    gstate = np.ascontiguousarray(g["state"]).view(oracle.PATH_STATE_DTYPE).reshape(-1)
+    assert oracle.state_fields_equal(gstate, state) == []
+    assert oracle.images_equal(g["image"], img)
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS))
+def test_oracle_equals_reference_build(prt, oracle, variant):
+    """different size / frame count / camera than the goldens, straight against oracle/_ref"""
+    if not oracle.ref_available(variant):
+        pytest.skip("oracle/_ref not built (only possible where /root/reference exists)")
+    W, H, frames = 45, 27, 70
+    scene, cfg, cam, env = setup(prt, variant, W, H)
+    cam = prt.orbit_camera(W, H, d_yaw=-0.3, d_pitch=0.15, d_radius=-0.1)
+    seeds = prt.seed_pairs(frames)
+    rstate, rimg = oracle.RefOracle(variant).render(scene.desc, bytes(cam), W, H, seeds, env=env, threads=4)
+    state, img = oracle.Restatement().render(cfg, scene.desc, cam, W, H, seeds, env=env, threads=4)
+    assert oracle.state_fields_equal(rstate, state) == []
+    assert oracle.images_equal(rimg, img)
+
+
+def test_reference_shadow_stack_never_needed_more_than_eight(prt, oracle):
+    """the reference's any-hit stack has 8 entries and no guard; the _ref build raises
+    it to 64.  On the teapot scenes the deepest any-hit stack ever used stays below 8, so the patched
+    and the original kernel are the same function on every fixture."""
+    scene, cfg, cam, env = setup(prt, "cornell_coat", 64, 48)
+    rs = oracle.Restatement()
+    rs.render(cfg, scene.desc, cam, 64, 48, prt.seed_pairs(64), threads=4)
+    max_stack, max_shadow = rs.last_diag
+    assert 0 < max_shadow <= 8 and max_stack <= 64
+
+
+def test_pixels_are_independent_tiles_and_row_blocks(prt, oracle):
+    W, H, frames = 40, 37, 40
+    scene, cfg, cam, env = setup(prt, "cornell_diffuse", W, H)
+    seeds = prt.seed_pairs(frames)
+    rs = oracle.Restatement()
+    fs, fi = rs.render(cfg, scene.desc, cam, W, H, seeds, threads=4)
+    fs = fs.reshape(H, W)
+    s1, i1 = rs.render(cfg, scene.desc, cam, W, H, seeds, row0=10, rows=9, threads=2)
+    assert oracle.state_fields_equal(fs[10:19].reshape(-1), s1) == [] and oracle.images_equal(fi[10:19], i1)
+    for part in range(3):
+        rows = np.array([y for y in range(H) if (y // 16) % 3 == part])
+        s2, i2 = rs.render(cfg, scene.desc, cam, W, H, seeds, blocks=(16, 3, part), threads=2)
+        assert oracle.state_fields_equal(fs[rows].reshape(-1), s2) == [] and oracle.images_equal(fi[rows], i2)
+
+
+def test_frame_batches_compose(prt, oracle):
+    W, H = 24, 16
+    scene, cfg, cam, env = setup(prt, "cornell_coat", W, H)
+    seeds = prt.seed_pairs(50)
+    rs = oracle.Restatement()
+    s_all, i_all = rs.render(cfg, scene.desc, cam, W, H, seeds, threads=2)
+    s, _ = rs.render(cfg, scene.desc, cam, W, H, seeds[:2 * 20], threads=2)
+    s, i = rs.render(cfg, scene.desc, cam, W, H, seeds[2 * 20:], first_frame=21, state=s, threads=2)
+    assert oracle.state_fields_equal(s_all, s) == [] and oracle.images_equal(i_all, i)
+
+
+def test_spp_rule_properties(prt, oracle):
+    W, H, spp = 32, 20, 5
+    scene, cfg, cam, env = setup(prt, "cornell_roughcond", W, H)
+    seeds = prt.seed_pairs(spp * cfg.max_bounces + 64)
+    state, img = oracle.Restatement().render(cfg, scene.desc, cam, W, H, seeds, spp_limit=spp, threads=4)
+    assert (state["samples"] == spp).all() and (state["reset"] != 0).all()
+    assert (state["acc"][:, 3] >= spp).all() and (state["acc"][:, 3] <= spp * (cfg.max_bounces + 1)).all()
+    assert np.allclose(img[..., 3].reshape(-1), state["acc"][:, 3] / spp)              # alpha = segments / samples (Q19)
+    assert np.isfinite(img).all() and (img[..., :3] >= 0).all()
