@@ -60,6 +60,10 @@ def build(verbose=False, extra_hip_flags=()):
     lib = os.path.join(HERE, "libprt.so")
     if (not os.path.exists(lib)) or any(os.path.getmtime(o) > os.path.getmtime(lib) for o in objs):
         run([HIPCC, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", lib] + objs)
+    exe = os.path.join(HERE, "prt_render")
+    src = os.path.join(CSRC, "host", "prt_render.cpp")
+    if newer(src, exe, headers + [lib]):
+        run([HOSTCXX] + COMMON + [src, "-o", exe, "-L" + HERE, "-lprt", "-Wl,-rpath,$ORIGIN"])
     return lib
 
 
