@@ -375,8 +375,8 @@ static unsigned frames_per_launch() {
     static unsigned v = 0;
     if (!v) {
         const char* e = std::getenv("PRT_FRAMES_PER_LAUNCH");
-        v = e ? (unsigned)std::atoi(e) : 32u;
-        if (v == 0) v = 32u;
+        v = e ? (unsigned)std::atoi(e) : 128u;   // measured on MI355X: 32 -> 3.82, 64 -> 3.95, 128 -> 4.01 G segments/s
+        if (v == 0) v = 128u;
     }
     return v;
 }
