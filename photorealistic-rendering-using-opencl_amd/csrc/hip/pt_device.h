@@ -201,8 +201,27 @@ PT_DEV bool hit_triangle(const TriGeom* __restrict__ tg, unsigned slot, const Ra
 }
 
 #ifndef PT_STACK_DEPTH
-#define PT_STACK_DEPTH 64      // the reference's closest-hit stack size (bvh.cl:131); deeper trees spill to `overflow`
+#define PT_STACK_DEPTH 64      // the reference's closest-hit stack size (bvh.cl:131)
 #endif
+#ifndef PT_LDS_STACK
+#define PT_LDS_STACK 32        // entries per lane kept in LDS ([level][thread]: conflict-free, 32 KiB per 256-thread workgroup); deeper levels go to scratch
+#endif
+
+// Traversal stack: a pop sits on the critical path of the walk (pop -> node index -> node fetch), so
+// the first PT_LDS_STACK levels live in LDS (~64-cycle round trip) instead of scratch memory.
+struct TravStack {
+    unsigned* lds;         // this lane's column: level l is lds[l * stride]
+    unsigned stride;       // threads per workgroup
+    unsigned* deep;        // scratch for levels >= PT_LDS_STACK
+    PT_DEV void put(int sp, unsigned v) const {
+        if (sp < PT_LDS_STACK) lds[(unsigned)sp * stride] = v;
+        else if (sp < PT_STACK_DEPTH) deep[sp - PT_LDS_STACK] = v;
+    }
+    PT_DEV unsigned get(int sp) const {
+        if (sp < PT_LDS_STACK) return lds[(unsigned)sp * stride];
+        return deep[(sp < PT_STACK_DEPTH ? sp : PT_STACK_DEPTH - 1) - PT_LDS_STACK];
+    }
+};
 
 // One body for bvh.cl:132-206 (closest hit) and :43-114 (any hit).  Returns true if (closest)
 // a triangle was accepted / (any) a triangle closer than ray.t exists.  Same visiting order as
@@ -232,7 +251,7 @@ PT_DEV PairTest test_pair(const NodePair* __restrict__ pairs, unsigned node, con
     return r;
 }
 
-PT_DEV bool traverse(const DevScene& sc, const bool ANY_HIT, const Ray& ray, float& best_t, TriHit& th, unsigned* stack) {
+PT_DEV bool traverse(const DevScene& sc, const bool ANY_HIT, const Ray& ray, float& best_t, TriHit& th, const TravStack& stack) {
     const RayPre p = ray_pre(ray);
     bool found = false;
     if (sc.root_is_leaf) {
@@ -263,13 +282,13 @@ PT_DEV bool traverse(const DevScene& sc, const bool ANY_HIT, const Ray& ray, flo
         } else if (go0) {
             unsigned nearc = meta.x, farc = meta.z;
             if (entry0 > entry1) { nearc = meta.z; farc = meta.x; }
-            if (sp < PT_STACK_DEPTH) stack[sp] = farc;
+            stack.put(sp, farc);
             ++sp;
             node = nearc;
         } else {
             if (sp == 0) break;
             --sp;
-            node = stack[sp < PT_STACK_DEPTH ? sp : PT_STACK_DEPTH - 1];
+            node = stack.get(sp);
         }
     }
     return found;
@@ -340,7 +359,7 @@ struct WgShared {
 #endif
 
 template <int BLOCK>
-PT_DEV TravRes wg_traverse(const DevScene& sc, WgShared<BLOCK>& sm, unsigned& parity, const TravReq& rq, unsigned* stack) {
+PT_DEV TravRes wg_traverse(const DevScene& sc, WgShared<BLOCK>& sm, unsigned& parity, const TravReq& rq, const TravStack& stack) {
     TravRes res;
     res.found = false; res.t = rq.tmax;
     res.th.u = res.th.v = res.th.w = 0.0f; res.th.slot = 0;
@@ -1033,7 +1052,7 @@ struct Path {
 // MATS: compile-time ACTIVE_MATS (0 = generic); MEDIUM: compile-time GLOBAL_MEDIUM.
 template <unsigned MATS, bool MEDIUM, int BLOCK>
 PT_DEV void radiance_segment(const DevScene& sc, WgShared<BLOCK>& sm, unsigned& parity, const bool live,
-                             Ray& ray, Path& st, Rng& rng, unsigned* stack) {
+                             Ray& ray, Path& st, Rng& rng, const TravStack& stack) {
     const unsigned am = active_mats<MATS>(sc);
     f3 emission = splat(0.0f);
     float alpha = 1.0f;

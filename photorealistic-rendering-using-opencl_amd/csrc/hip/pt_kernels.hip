@@ -62,7 +62,10 @@ __global__ __launch_bounds__(PT_BLOCK, PT_MIN_WAVES) void render_kernel(const De
         st.trans = e.z & 0xffffu; st.scatters = e.z >> 16;
         st.wasSpecular = (e.w & 1u) != 0; st.reset = (e.w & 2u) != 0;
     }
-    unsigned stack[PT_STACK_DEPTH];
+    __shared__ unsigned lds_stack[PT_LDS_STACK * PT_BLOCK];
+    unsigned deep_stack[PT_STACK_DEPTH - PT_LDS_STACK];
+    TravStack stack;
+    stack.lds = lds_stack + threadIdx.x; stack.stride = PT_BLOCK; stack.deep = deep_stack;
     bool ran = false;
     for (unsigned f = 0; f < fa.n_frames; ++f) {
         const bool live = valid && !(fa.spp_limit && st.reset && st.samples >= fa.spp_limit);   // frozen = the "N spp" rule
