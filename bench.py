@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--scene", default="cornell_diffuse.json")
+    ap.add_argument("--env", default="", choices=["", "sky"], help="sky = the procedural 1024x512 HDR stand-in (configs 3, 4)")
+    ap.add_argument("--phase", default="isotropic", choices=["isotropic", "hg"], help="phase function of the global medium (config 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -76,14 +78,19 @@ def main():
         ge.build()
 
     W, H, spp = a.width, a.height, a.spp
+    if "dragon" in a.scene:
+        prt.ensure_dragon_standin()
     scene = prt.HostScene(a.scene)
     cfg = scene.config()
+    cfg.phase_function = 1 if a.phase == "hg" else 0
     cam = prt.default_camera(W, H)
     max_frames = max(64, spp * max(cfg.max_bounces, 8) + 64)      # a path has at most max_bounces (+1) segments
     seeds = prt.seed_pairs(max_frames)
 
     r = prt.Renderer(cfg, device=local_rank)
     r.upload_scene(scene)
+    if a.env == "sky":
+        r.upload_envmap(prt.make_sky(1024, 512))
     r.set_camera(cam)
     stream = torch.cuda.current_stream()
     r.set_stream(stream.cuda_stream)
@@ -167,7 +174,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "scenes/cornell (teapot DIFF = Lambert + sphere area light) %dx%d %dspp, %d x MI355X" % (W, H, spp, world),
+            "config": {"workload": "%s %dx%d %dspp%s%s, %d x MI355X" % (
+                           "scenes/cornell (teapot DIFF = Lambert + sphere area light)" if a.scene == "cornell_diffuse.json" else a.scene,
+                           W, H, spp, " + procedural HDR env" if a.env else "", " HG phase" if a.phase == "hg" else "", world),
                        "scene": a.scene, "width": W, "height": H, "spp": spp,
                        "mean_path_length": round(total_segments / max(total_samples, 1.0), 4),
                        "segments_per_step": total_segments,
@@ -179,14 +188,14 @@ def main():
                          "gsegments_per_s": round(own_segments * steps / (kernel_ms * 1e-3) / 1e9, 4) if kernel_ms > 0 else 0.0},
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(prt, a.scene)
+            out["cpu_baseline"] = cpu_baseline(prt, a)
         print(json.dumps(out))
     r.close()
     if world > 1:
         dist.destroy_process_group()
 
 
-def cpu_baseline(prt, scene_json):
+def cpu_baseline(prt, a):
     """oracle/pt_oracle.c timed on the host cores: 960x540 (1/2 of the frame in each dimension,
     same camera) at 96 spp of the same scene -- about 10-30 s of CPU work on the GPU box."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -197,13 +206,15 @@ def cpu_baseline(prt, scene_json):
     except Exception:
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, 64))
-    scene = prt.HostScene(scene_json)
+    scene = prt.HostScene(a.scene)
     cfg = scene.config()
+    cfg.phase_function = 1 if a.phase == "hg" else 0
     cam = prt.default_camera(W, H)
     seeds = prt.seed_pairs(spp * max(cfg.max_bounces, 8) + 64)
+    env = prt.make_sky(1024, 512) if a.env == "sky" else None
     rs = O.Restatement()
     t0 = time.perf_counter()
-    state, _ = rs.render(cfg, scene.desc, cam, W, H, seeds, spp_limit=spp, threads=cores)
+    state, _ = rs.render(cfg, scene.desc, cam, W, H, seeds, env=env, spp_limit=spp, threads=cores)
     dt = time.perf_counter() - t0
     assert (state["samples"] == spp).all()
     return {"value": round(W * H * spp / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",

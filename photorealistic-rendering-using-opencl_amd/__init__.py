@@ -22,7 +22,7 @@ REPO = os.path.dirname(HERE)
 SCENES_DIR = os.path.join(REPO, "scenes")
 MODELS_DIR = os.path.join(SCENES_DIR, "models")
 
-__all__ = ["HostScene", "Renderer", "default_camera", "orbit_camera", "seed_pairs", "make_sky", "PrtError",
+__all__ = ["ensure_dragon_standin", "HostScene", "Renderer", "default_camera", "orbit_camera", "seed_pairs", "make_sky", "PrtError",
            "Camera", "Config", "SceneDesc", "Stats", "PATH_STATE_DTYPE", "SCENES_DIR", "MODELS_DIR", "build"]
 
 
@@ -37,6 +37,19 @@ def build(verbose=False):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod.build(verbose=verbose)
+
+
+def ensure_dragon_standin():
+    """scenes/cornell_dragon.json needs scenes/models/dragon_standin.prtmesh (62 MB, ~871 k triangles):
+    generated on demand by scenes/make_dragon_standin.py, never committed"""
+    path = os.path.join(MODELS_DIR, "dragon_standin.prtmesh")
+    if not os.path.exists(path):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("_make_dragon", os.path.join(SCENES_DIR, "make_dragon_standin.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.write(path)
+    return path
 
 
 class HostScene:

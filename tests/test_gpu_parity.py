@@ -200,3 +200,19 @@ def test_errors_are_reported_not_fatal(prt):
     with pytest.raises(prt.PrtError):
         prt.Renderer(cfg, device=4096)
     r.close()
+
+
+def test_dragon_standin_matches_oracle(prt, oracle):
+    """871 k triangles, BVH depth 23: deep stacks (LDS + scratch levels), MALL-resident geometry"""
+    prt.ensure_dragon_standin()
+    W, H, frames = 128, 72, 48
+    scene = prt.HostScene("cornell_dragon.json")
+    cfg, cam, seeds = scene.config(), prt.default_camera(W, H), prt.seed_pairs(frames)
+    r = prt.Renderer(cfg, device=0)
+    r.upload_scene(scene)
+    r.set_camera(cam)
+    r.resize(W, H)
+    r.render_frames(seeds)
+    ostate, oimg = oracle.Restatement().render(cfg, scene.desc, cam, W, H, seeds, threads=16)
+    _assert_same(oracle, ostate, oimg, r.read_state(), r.read_framebuffer(), "dragon stand-in")
+    r.close()

@@ -89,3 +89,20 @@ def test_spp_rule_properties(prt, oracle):
     assert (state["acc"][:, 3] >= spp).all() and (state["acc"][:, 3] <= spp * (cfg.max_bounces + 1)).all()
     assert np.allclose(img[..., 3].reshape(-1), state["acc"][:, 3] / spp)              # alpha = segments / samples (Q19)
     assert np.isfinite(img).all() and (img[..., :3] >= 0).all()
+
+
+def test_dragon_standin_oracle_equals_reference_build(prt, oracle):
+    """config 5 geometry (871 k triangles, tree depth 23): needs any-hit stack depths > 8, where the
+    unpatched reference is undefined; the reference build runs with the raised stack"""
+    if not oracle.ref_available("cornell_diffuse"):
+        pytest.skip("oracle/_ref not built")
+    prt.ensure_dragon_standin()
+    W, H, frames = 40, 24, 40
+    scene = prt.HostScene("cornell_dragon.json")
+    assert scene.desc.triangle_count == 871200
+    cfg, cam, seeds = scene.config(), prt.default_camera(W, H), prt.seed_pairs(frames)
+    rstate, rimg = oracle.RefOracle("cornell_diffuse").render(scene.desc, bytes(cam), W, H, seeds, threads=8)   # same specialisation: LIGHT|DIFF
+    rs = oracle.Restatement()
+    state, img = rs.render(cfg, scene.desc, cam, W, H, seeds, threads=8)
+    assert oracle.state_fields_equal(rstate, state) == [] and oracle.images_equal(rimg, img)
+    assert rs.last_diag[1] > 8          # the any-hit stack really goes deeper than the reference's 8 entries
