@@ -203,38 +203,37 @@ PT_DEV bool hit_triangle(const TriGeom* __restrict__ tg, unsigned slot, const Ra
 #ifndef PT_STACK_DEPTH
 #define PT_STACK_DEPTH 64      // the reference's closest-hit stack size (bvh.cl:131)
 #endif
-#ifndef PT_LDS_STACK
-#define PT_LDS_STACK 32        // entries per lane kept in LDS ([level][thread]: conflict-free, 32 KiB per 256-thread workgroup); deeper levels go to scratch
-#endif
-
 // Traversal stack: a pop sits on the critical path of the walk (pop -> node index -> node fetch), so
-// the first PT_LDS_STACK levels live in LDS (~64-cycle round trip) instead of scratch memory.
+// the first levels live in LDS (~64-cycle round trip, [level][thread] layout = conflict-free)
+// instead of scratch memory; deeper levels spill to a scratch array.
 struct TravStack {
     unsigned* lds;         // this lane's column: level l is lds[l * stride]
     unsigned stride;       // threads per workgroup
-    unsigned* deep;        // scratch for levels >= PT_LDS_STACK
+    unsigned* deep;        // scratch for levels >= lds_levels
+    int lds_levels;
     PT_DEV void put(int sp, unsigned v) const {
-        if (sp < PT_LDS_STACK) lds[(unsigned)sp * stride] = v;
-        else if (sp < PT_STACK_DEPTH) deep[sp - PT_LDS_STACK] = v;
+        if (sp < lds_levels) lds[(unsigned)sp * stride] = v;
+        else if (sp < PT_STACK_DEPTH) deep[sp - lds_levels] = v;
     }
     PT_DEV unsigned get(int sp) const {
-        if (sp < PT_LDS_STACK) return lds[(unsigned)sp * stride];
-        return deep[(sp < PT_STACK_DEPTH ? sp : PT_STACK_DEPTH - 1) - PT_LDS_STACK];
+        if (sp < lds_levels) return lds[(unsigned)sp * stride];
+        return deep[(sp < PT_STACK_DEPTH ? sp : PT_STACK_DEPTH - 1) - lds_levels];
     }
 };
 
-// One body for bvh.cl:132-206 (closest hit) and :43-114 (any hit).  Returns true if (closest)
-// a triangle was accepted / (any) a triangle closer than ray.t exists.  Same visiting order as
-// the reference: both children's boxes are tested against the CURRENT ray.t before either leaf
-// is tested; leaf children are tested immediately, left first; of two inner children the nearer
-// (by entry distance, ties -> left) is followed and the other pushed.
-// Slab test of both children of one NodePair against the ray (bvh.cl:11-26), `best_t` = ray->t.
-struct PairTest { float entry0, entry1; bool go0, go1; uint4 meta; };
-PT_DEV PairTest test_pair(const NodePair* __restrict__ pairs, unsigned node, const RayPre& p, float best_t) {
+struct PairData { float4 b0, b1, b2; uint4 meta; };
+PT_DEV PairData load_pair(const NodePair* __restrict__ pairs, unsigned node) {
     const float4* q = reinterpret_cast<const float4*>(pairs + node);
-    const float4 b0 = q[0], b1 = q[1], b2 = q[2];
+    PairData d;
+    d.b0 = q[0]; d.b1 = q[1]; d.b2 = q[2];
+    d.meta = *reinterpret_cast<const uint4*>(q + 3);
+    return d;
+}
+// Slab test of both children of one NodePair against the ray (bvh.cl:11-26), `best_t` = ray->t.
+struct PairTest { float entry0, entry1; bool go0, go1; };
+PT_DEV PairTest test_pair(const PairData& d, const RayPre& p, float best_t) {
+    const float4 b0 = d.b0, b1 = d.b1, b2 = d.b2;
     PairTest r;
-    r.meta = *reinterpret_cast<const uint4*>(q + 3);
     // child 0: x = b0.xy, y = b0.zw, z = b1.xy ; child 1: x = b1.zw, y = b2.xy, z = b2.zw
     float e0x = prt_fma(p.nx ? b0.y : b0.x, p.ix, p.sx), x0x = prt_fma(p.nx ? b0.x : b0.y, p.ix, p.sx);
     float e0y = prt_fma(p.ny ? b0.w : b0.z, p.iy, p.sy), x0y = prt_fma(p.ny ? b0.z : b0.w, p.iy, p.sy);
@@ -251,47 +250,66 @@ PT_DEV PairTest test_pair(const NodePair* __restrict__ pairs, unsigned node, con
     return r;
 }
 
-PT_DEV bool traverse(const DevScene& sc, const bool ANY_HIT, const Ray& ray, float& best_t, TriHit& th, const TravStack& stack) {
-    const RayPre p = ray_pre(ray);
-    bool found = false;
-    if (sc.root_is_leaf) {
-        for (unsigned i = sc.root_leaf_first; i < sc.root_leaf_first + sc.root_leaf_count; ++i) {
-            if (hit_triangle(sc.tri_geom, i, ray, best_t, th)) { found = true; if (ANY_HIT) return true; }
-        }
-        return found;
+// One step of bvh.cl:144-196 (closest hit) / :54-104 (any hit) at `node`, pair record already
+// loaded.  Same visiting order as the reference: both children's boxes are tested against the
+// CURRENT best_t before either leaf is tested; leaf children are tested immediately, left first;
+// of two inner children the nearer (by entry distance, ties -> left) is followed and the other
+// pushed.  Returns false when the walk is over (any-hit: `found` tells why).
+PT_DEV bool walk_step(const DevScene& sc, const bool ANY_HIT, const PairData& d, const RayPre& p, const Ray& ray,
+                      float& best_t, TriHit& th, bool& found, unsigned& node, int& sp, const TravStack& stack) {
+    const PairTest pt = test_pair(d, p, best_t);
+    const uint4 meta = d.meta;
+    bool go0 = pt.go0, go1 = pt.go1;
+    if (go0 && meta.y != 0xFFFFFFFFu) {                          // left child is a leaf
+        for (unsigned i = meta.x; i < meta.x + meta.y; ++i)
+            if (hit_triangle(sc.tri_geom, i, ray, best_t, th)) { found = true; if (ANY_HIT) return false; }
+        go0 = false;
     }
+    if (go1 && meta.w != 0xFFFFFFFFu) {
+        for (unsigned i = meta.z; i < meta.z + meta.w; ++i)
+            if (hit_triangle(sc.tri_geom, i, ray, best_t, th)) { found = true; if (ANY_HIT) return false; }
+        go1 = false;
+    }
+    if (go0 != go1) {
+        node = go0 ? meta.x : meta.z;
+    } else if (go0) {
+        unsigned nearc = meta.x, farc = meta.z;
+        if (pt.entry0 > pt.entry1) { nearc = meta.z; farc = meta.x; }
+        stack.put(sp, farc);
+        ++sp;
+        node = nearc;
+    } else {
+        if (sp == 0) return false;
+        --sp;
+        node = stack.get(sp);
+    }
+    return true;
+}
+
+struct TravReq { bool want; f3 o, d; float tmax; };
+struct TravRes { bool found; float t; TriHit th; };
+
+// bvh.cl:132-206 (closest hit) / :43-114 (any hit): returns true if (closest) a triangle was accepted,
+// (any) a triangle closer than rq.tmax exists.
+PT_DEV TravRes walk(const DevScene& sc, const bool ANY_HIT, const TravReq& rq, const TravStack& stack) {
+    TravRes res;
+    res.found = false; res.t = rq.tmax;
+    res.th.u = res.th.v = res.th.w = 0.0f; res.th.slot = 0;
+    Ray ray;
+    ray.origin = rq.o; ray.dir = rq.d;
+    if (sc.root_is_leaf) {                                       // tiny meshes: no tree to walk
+        for (unsigned i = sc.root_leaf_first; i < sc.root_leaf_first + sc.root_leaf_count; ++i)
+            if (hit_triangle(sc.tri_geom, i, ray, res.t, res.th)) { res.found = true; if (ANY_HIT) return res; }
+        return res;
+    }
+    const RayPre p = ray_pre(ray);
     unsigned node = 0;
     int sp = 0;
     for (;;) {
-        const PairTest pt = test_pair(sc.pairs, node, p, best_t);
-        const uint4 meta = pt.meta;
-        const float entry0 = pt.entry0, entry1 = pt.entry1;
-        bool go0 = pt.go0, go1 = pt.go1;
-        if (go0 && meta.y != 0xFFFFFFFFu) {                      // left child is a leaf
-            for (unsigned i = meta.x; i < meta.x + meta.y; ++i)
-                if (hit_triangle(sc.tri_geom, i, ray, best_t, th)) { found = true; if (ANY_HIT) return true; }
-            go0 = false;
-        }
-        if (go1 && meta.w != 0xFFFFFFFFu) {
-            for (unsigned i = meta.z; i < meta.z + meta.w; ++i)
-                if (hit_triangle(sc.tri_geom, i, ray, best_t, th)) { found = true; if (ANY_HIT) return true; }
-            go1 = false;
-        }
-        if (go0 != go1) {
-            node = go0 ? meta.x : meta.z;
-        } else if (go0) {
-            unsigned nearc = meta.x, farc = meta.z;
-            if (entry0 > entry1) { nearc = meta.z; farc = meta.x; }
-            stack.put(sp, farc);
-            ++sp;
-            node = nearc;
-        } else {
-            if (sp == 0) break;
-            --sp;
-            node = stack.get(sp);
-        }
+        const PairData d = load_pair(sc.pairs, node);
+        if (!walk_step(sc, ANY_HIT, d, p, ray, res.t, res.th, res.found, node, sp, stack)) break;
     }
-    return found;
+    return res;
 }
 
 // ---- sphere / quad, kernels/geometry/sphere.cl:5-41, quad.cl:11-38 ------------------------------
@@ -324,106 +342,6 @@ PT_DEV bool hit_quad(const DevQuad& qd, const Ray& ray, float& best_t, f3& q_out
     best_t = rt;
     q_out = q;
     return true;
-}
-
-// ---- workgroup-cooperative BVH traversal ------------------------------------------------------------
-// Measured on cornell at 1080p: a ray needs 2.9 node steps on average (most rays never enter the
-// teapot's boxes), yet nearly every wave contains a few rays that walk 30+ steps, so with one ray
-// per lane the whole wave pays the deepest walk (2.4 G segments/s with the teapot, 15 G without).
-// Therefore traversal is a WORKGROUP stage: every lane does the root step inline (bvh.cl:144-157
-// for node 0: the exact test the full walk starts with); rays that enter a child box are compacted
-// through LDS (ballot + one LDS atomic per wave) into dense waves, which walk them from the root
-// with the reference's exact visiting order and write the result back to the owner's LDS slot.
-// Two barriers per stage; three stages per path segment (closest, probe, shadow).
-struct TravReq { bool want, any; f3 o, d; float tmax; };
-struct TravRes { bool found; float t; TriHit th; };
-
-template <int BLOCK>
-struct WgShared {
-    float4 q0[BLOCK];        // queue: origin.xyz, tmax
-    float4 q1[BLOCK];        // queue: dir.xyz, bits(owner | any << 31)
-    float4 r0[BLOCK];        // result by owner: t, u, v, w
-    unsigned r1[BLOCK];      // result by owner: slot | found << 31
-    unsigned count[2];       // queue length, double-buffered by stage parity
-};
-
-// PT_COOPERATIVE = 0 (default): every lane walks its own ray (no LDS, no barriers).
-// PT_COOPERATIVE = 1: the workgroup-regrouped walk described above.  Measured on MI355X
-// (cornell_diffuse 1080p): regrouping removes ~6x of the traversal INSTRUCTIONS but the stage then
-// idles most waves at its two barriers while one or two waves walk a latency-bound chain, and the
-// register-limited occupancy (128 VGPRs -> 16 waves/CU) leaves nothing else to run: 1.7-2.0 G
-// segments/s against 2.4 G for the per-lane walk.  Kept as the starting point of the wavefront
-// split (a lean traversal kernel fed by compacted queues), see DESIGN.md.
-#ifndef PT_COOPERATIVE
-#define PT_COOPERATIVE 0
-#endif
-
-template <int BLOCK>
-PT_DEV TravRes wg_traverse(const DevScene& sc, WgShared<BLOCK>& sm, unsigned& parity, const TravReq& rq, const TravStack& stack) {
-    TravRes res;
-    res.found = false; res.t = rq.tmax;
-    res.th.u = res.th.v = res.th.w = 0.0f; res.th.slot = 0;
-#if !PT_COOPERATIVE
-    (void)sm; (void)parity;
-    if (rq.want) {
-        Ray ray;
-        ray.origin = rq.o; ray.dir = rq.d;
-        res.found = traverse(sc, rq.any, ray, res.t, res.th, stack);
-    }
-    return res;
-#else
-    const unsigned lane = threadIdx.x & 63u;
-    bool deep = false;
-    if (rq.want) {
-        Ray ray;
-        ray.origin = rq.o; ray.dir = rq.d;
-        if (sc.root_is_leaf) {
-            res.found = traverse(sc, rq.any, ray, res.t, res.th, stack);      // tiny meshes: nothing to regroup
-        } else {
-            const PairTest pt = test_pair(sc.pairs, 0u, ray_pre(ray), rq.tmax);
-            deep = pt.go0 || pt.go1;     // otherwise the walk ends after its first step with nothing found
-        }
-    }
-    const unsigned long long m = __ballot(deep);
-    if (m) {
-        unsigned base = 0;
-        if (lane == (unsigned)__builtin_ctzll(m)) base = atomicAdd(&sm.count[parity], (unsigned)__popcll(m));
-        base = (unsigned)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(m));
-        if (deep) {
-            const unsigned idx = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-            sm.q0[idx] = make_float4(rq.o.x, rq.o.y, rq.o.z, rq.tmax);
-            sm.q1[idx] = make_float4(rq.d.x, rq.d.y, rq.d.z, prt_u2f(threadIdx.x | (rq.any ? 0x80000000u : 0u)));
-        }
-    }
-    __syncthreads();
-    const unsigned n = sm.count[parity];
-    if (threadIdx.x == 0) sm.count[parity ^ 1u] = 0;                          // for the next stage
-    for (unsigned base = (threadIdx.x & ~63u); base < n; base += BLOCK) {     // dense waves walk the queue
-        const unsigned i = base + lane;
-        if (i < n) {
-            const float4 a = sm.q0[i], b = sm.q1[i];
-            const unsigned ob = prt_f2u(b.w);
-            Ray ray;
-            ray.origin = F3(a.x, a.y, a.z); ray.dir = F3(b.x, b.y, b.z);
-            float t = a.w;
-            TriHit th;
-            th.u = th.v = th.w = 0.0f; th.slot = 0;
-            const bool found = traverse(sc, (ob >> 31) != 0, ray, t, th, stack);
-            const unsigned owner = ob & 0x7fffffffu;
-            sm.r0[owner] = make_float4(t, th.u, th.v, th.w);
-            sm.r1[owner] = th.slot | (found ? 0x80000000u : 0u);
-        }
-    }
-    __syncthreads();
-    if (deep) {
-        const float4 r = sm.r0[threadIdx.x];
-        const unsigned s1 = sm.r1[threadIdx.x];
-        res.found = (s1 >> 31) != 0;
-        res.t = r.x; res.th.u = r.y; res.th.v = r.z; res.th.w = r.w; res.th.slot = s1 & 0x7fffffffu;
-    }
-    parity ^= 1u;
-    return res;
-#endif
 }
 
 // ---- the rest of intersect_scene, kernels/intersect.cl:167-236, given the BVH result ----------------
@@ -1040,34 +958,48 @@ struct Path {
     bool wasSpecular, reset;
 };
 
+// shadow(), kernels/intersect.cl:94-152: true = unoccluded.  The BVH, sphere and quad tests are
+// independent (no state, no RNG, the any-hit walk never shrinks ray.t), so the boolean does not depend on
+// their order: the 7 primitives are tested first and the tree is only walked when they do not occlude.
+PT_DEV bool shadow(const DevScene& sc, const f3 o, const f3 d, const float tmax, const TravStack& stack) {
+    if (!finish_shadow(sc, o, d, tmax)) return false;
+    TravReq rq;
+    rq.want = true; rq.o = o; rq.d = d; rq.tmax = tmax;
+    return !walk(sc, true, rq, stack).found;
+}
+
 // ---- one segment: kernels/integrators/pathtracing.cl:4-120 + base.cl:31-260 -----------------------------
-// Every lane of the workgroup calls this in lock step (`live` = the lane has a pixel that is not
-// frozen); the three traversals of a segment are workgroup stages (wg_traverse), everything else
-// is per lane in the reference's order, so every RNG draw happens exactly where it does there.
-//   stage 1  closest hit of the path ray                                  (intersect_scene, pathtracing.cl:27)
-//   stage 2  surface: closest hit of the BSDF-sampled probe ray           (bsdfSample, base.cl:54-57)
-//            medium scatter: any-hit of the light shadow ray              (volumeLightSample, base.cl:219)
-//   stage 3  surface: any-hit of the light shadow ray                     (lightSample, base.cl:115)
-//            medium scatter: closest hit of the phase-sampled probe ray   (volumePhaseSample, base.cl:247)
+// Per lane, in the reference's order, so every RNG draw happens exactly where it does there.  Walks:
+//   W1  closest hit of the path ray (intersect_scene, pathtracing.cl:27) -- skipped when the hit cache
+//       holds it (the previous segment's probe)
+//   W2  closest hit of the BSDF-sampled probe ray (bsdfSample, base.cl:54-57) or of the phase-sampled
+//       probe ray (volumePhaseSample, base.cl:247)
+//   W3  any-hit of the light shadow ray (lightSample base.cl:115, volumeLightSample base.cl:219).  Its
+//       result only selects the radiance added to acc, so for a medium scatter (where the reference walks
+//       it BEFORE the probe) it runs last here; no RNG draw or path state depends on it.
 // MATS: compile-time ACTIVE_MATS (0 = generic); MEDIUM: compile-time GLOBAL_MEDIUM.
-template <unsigned MATS, bool MEDIUM, int BLOCK>
-PT_DEV void radiance_segment(const DevScene& sc, WgShared<BLOCK>& sm, unsigned& parity, const bool live,
-                             Ray& ray, Path& st, Rng& rng, const TravStack& stack) {
+template <unsigned MATS, bool MEDIUM>
+PT_DEV void radiance_segment(const DevScene& sc, Ray& ray, Path& st, Rng& rng, const TravStack& stk) {
     const unsigned am = active_mats<MATS>(sc);
     f3 emission = splat(0.0f);
     float alpha = 1.0f;
-    bool done = !live;
+    bool done = false;
 
-    // ---------------- stage 1
-    const bool cached = live && st.hc.valid;
-    TravReq rq;
-    rq.want = live && !cached; rq.any = false; rq.o = ray.origin; rq.d = ray.dir; rq.tmax = PT_INF;
-    const TravRes r1 = wg_traverse<BLOCK>(sc, sm, parity, rq, stack);
-
+    // ---------------- W1
     int mesh_id = -1;
-    bool didHit = false;
-    Mat mat;
-    mat.color = mat.eta = mat.k = splat(0.0f); mat.roughness = 0.0f; mat.t = mat.lobes = mat.dist = 0;
+    bool didHit;
+    if (st.hc.valid) {
+        didHit = st.hc.didHit; mesh_id = st.hc.mesh_id;
+        ray.t = st.hc.t; ray.normal = st.hc.normal; ray.pos = st.hc.pos; ray.backside = st.hc.backside;
+    } else {
+        TravReq rq;
+        rq.want = true; rq.o = ray.origin; rq.d = ray.dir; rq.tmax = PT_INF;
+        const TravRes r1 = walk(sc, false, rq, stk);
+        didHit = finish_closest(sc, ray, r1, mesh_id);
+    }
+    st.hc.valid = false;
+    const Mat mat = load_mat((mesh_id + 1) ? &sc.mats[mesh_id + 1] : &sc.mats[sc.n_meshes + 1]);
+
     enum { K_NONE = 0, K_SURFACE_MIS = 1, K_SCATTER = 2 };
     int kind = K_NONE;
     Event e;
@@ -1078,82 +1010,84 @@ PT_DEV void radiance_segment(const DevScene& sc, WgShared<BLOCK>& sm, unsigned& 
     ms.p = splat(0.0f); ms.weight = splat(1.0f); ms.exited = true;
     LightSample rec;
     rec.d = splat(0.0f); rec.dist = 0.0f; rec.pdf = 1.0f;
-    float fv = 0.0f;                 // phase function value (scatter)
+    PhaseSample ps;
+    ps.w = ps.weight = splat(0.0f); ps.pdf = 1.0f;
+    bool sh = false;                 // this segment has a shadow ray to decide
+    f3 sh_o = splat(0.0f), sh_d = splat(0.0f);
+    float sh_tmax = 0.0f;
+    f3 a_vis = splat(0.0f);          // scatter: the light-sample term if the shadow ray is unoccluded
+    f3 b_vis = splat(0.0f);          // surface: the same
     TravReq rq2;
-    rq2.want = false; rq2.any = false; rq2.o = rq2.d = splat(0.0f); rq2.tmax = PT_INF;
+    rq2.want = false; rq2.o = rq2.d = splat(0.0f); rq2.tmax = PT_INF;
 
-    if (live) {
-        if (cached) {
-            didHit = st.hc.didHit; mesh_id = st.hc.mesh_id;
-            ray.t = st.hc.t; ray.normal = st.hc.normal; ray.pos = st.hc.pos; ray.backside = st.hc.backside;
-        } else {
-            didHit = finish_closest(sc, ray, r1, mesh_id);
-        }
-        st.hc.valid = false;
-        mat = load_mat((mesh_id + 1) ? &sc.mats[mesh_id + 1] : &sc.mats[sc.n_meshes + 1]);
-        bool scattered = false;
-        if (MEDIUM) {
-            medium_sample_distance(sc, ms, ray, rng);
-            st.mask = st.mask * ms.weight;
-            if (!ms.exited && (int)st.scatters < sc.max_scattering_events) {
-                scattered = true;
-                kind = K_SCATTER;
-                st.scatters = (st.scatters + 1u) & 0xffffu;
-                st.wasSpecular = false;
-                // volumeLightSample, base.cl:194-230 (samples the light from ray.pos, not ms.p: SURVEY s9-Q4)
-                if (sample_light0(sc, ray.pos, rec, rng)) {
-                    fv = phase_value(sc, ray.dir, rec.d);
-                    const f3 f = splat(fv);
-                    if (!(dot(f, f) == 0.0f)) { rq2.want = true; rq2.any = true; rq2.o = ms.p; rq2.d = rec.d; rq2.tmax = rec.dist; }
+    bool scattered = false;
+    if (MEDIUM) {
+        medium_sample_distance(sc, ms, ray, rng);
+        st.mask = st.mask * ms.weight;
+        if (!ms.exited && (int)st.scatters < sc.max_scattering_events) {
+            scattered = true;
+            kind = K_SCATTER;
+            st.scatters = (st.scatters + 1u) & 0xffffu;
+            st.wasSpecular = false;
+            // volumeLightSample, base.cl:194-230 (samples the light from ray.pos, not ms.p: SURVEY s9-Q4)
+            if (sample_light0(sc, ray.pos, rec, rng)) {
+                const float fv = phase_value(sc, ray.dir, rec.d);
+                const f3 f = splat(fv);
+                if (!(dot(f, f) == 0.0f)) {
+                    sh = true; sh_o = ms.p; sh_d = rec.d; sh_tmax = rec.dist;
+                    const Mat lm = load_mat(&sc.mats[sc.light_mesh + 1]);
+                    const f3 tr = vexp(splat(sc.fog_sigma_t) * (-1.0f * rec.dist));
+                    const f3 contribution = tr * lm.color * f * power_heuristic(rec.pdf, fv);
+                    a_vis = contribution / rec.pdf;
                 }
             }
+            phase_sample(sc, ray.dir, ps, rng);                          // volumePhaseSample, base.cl:232-260
+            rq2.want = true; rq2.o = ms.p; rq2.d = ps.w; rq2.tmax = PT_INF;
         }
-        if (!scattered) {
-            if (!didHit) {
-                st.reset = true;
-                if (sc.alpha_testing) { emission = splat(0.0f); alpha = 0.0f; }
-                else emission = st.mask * env_lookup(sc, ray.dir);
-                done = true;
-            } else if ((am & PRT_MAT_LIGHT) && (mat.t & PRT_MAT_LIGHT)) {
-                if (st.wasSpecular) emission = emission + mat.color * st.mask;
-                st.reset = true;
-                done = true;
-            } else {
-                surface = true;
-                e.frame = make_frame(ray.normal);                       // makeLocalScatterEvent, base.cl:11-14
-                e.wi = to_local(e.frame, -ray.dir);
-                if ((am & PRT_MAT_LIGHT) && (mat.lobes & ~(PRT_LOBE_SPECULAR | PRT_LOBE_FORWARD) & 0xffu)) {
-                    kind = K_SURFACE_MIS;                               // handleSurface, base.cl:168-172
-                    if (!bsdf_sample2<MATS>(sc, e, ray, mat, rng)) {    // bsdfSample, base.cl:31-77
-                        terminate = true;
-                    } else {
-                        ray.origin = ray.pos;
-                        ray.dir = to_global(e.frame, e.wo);
-                        rq2.want = true; rq2.any = false; rq2.o = ray.origin; rq2.d = ray.dir; rq2.tmax = PT_INF;
-                    }
+    }
+    if (!scattered) {
+        if (!didHit) {
+            st.reset = true;
+            if (sc.alpha_testing) { emission = splat(0.0f); alpha = 0.0f; }
+            else emission = st.mask * env_lookup(sc, ray.dir);
+            done = true;
+        } else if ((am & PRT_MAT_LIGHT) && (mat.t & PRT_MAT_LIGHT)) {
+            if (st.wasSpecular) emission = emission + mat.color * st.mask;
+            st.reset = true;
+            done = true;
+        } else {
+            surface = true;
+            e.frame = make_frame(ray.normal);                           // makeLocalScatterEvent, base.cl:11-14
+            e.wi = to_local(e.frame, -ray.dir);
+            if ((am & PRT_MAT_LIGHT) && (mat.lobes & ~(PRT_LOBE_SPECULAR | PRT_LOBE_FORWARD) & 0xffu)) {
+                kind = K_SURFACE_MIS;                                   // handleSurface, base.cl:168-172
+                if (!bsdf_sample2<MATS>(sc, e, ray, mat, rng)) {        // bsdfSample, base.cl:31-77
+                    terminate = true;
                 } else {
-                    if (!bsdf_sample2<MATS>(sc, e, ray, mat, rng)) {    // base.cl:175-181
-                        st.reset = true;
-                        done = true;
-                        surface = false;
-                    } else {
-                        ray.origin = ray.pos;
-                        ray.dir = to_global(e.frame, e.wo);
-                    }
+                    ray.origin = ray.pos;
+                    ray.dir = to_global(e.frame, e.wo);
+                    rq2.want = true; rq2.o = ray.origin; rq2.d = ray.dir; rq2.tmax = PT_INF;
+                }
+            } else {
+                if (!bsdf_sample2<MATS>(sc, e, ray, mat, rng)) {        // base.cl:175-181
+                    st.reset = true;
+                    done = true;
+                    surface = false;
+                } else {
+                    ray.origin = ray.pos;
+                    ray.dir = to_global(e.frame, e.wo);
                 }
             }
         }
     }
 
-    // ---------------- stage 2
-    const TravRes r2 = wg_traverse<BLOCK>(sc, sm, parity, rq2, stack);
+    // ---------------- W2
+    TravRes r2;
+    r2.found = false; r2.t = PT_INF; r2.th.u = r2.th.v = r2.th.w = 0.0f; r2.th.slot = 0;
+    if (rq2.want) r2 = walk(sc, false, rq2, stk);
 
-    f3 a = splat(0.0f), b = splat(0.0f);
-    PhaseSample ps;
-    ps.w = ps.weight = splat(0.0f); ps.pdf = 1.0f;
-    TravReq rq3;
-    rq3.want = false; rq3.any = false; rq3.o = rq3.d = splat(0.0f); rq3.tmax = PT_INF;
     if (kind == K_SURFACE_MIS) {
+        f3 a = splat(0.0f);
         if (rq2.want) {                                                  // the probe ray, base.cl:54-75
             int mid;
             const bool hit2 = finish_closest(sc, ray, r2, mid);
@@ -1173,41 +1107,24 @@ PT_DEV void radiance_segment(const DevScene& sc, WgShared<BLOCK>& sm, unsigned& 
             e.wo = to_local(e.frame, rec.d);
             const f3 fr = bsdf_eval2<MATS>(sc, e, mat);
             if (!(dot(fr, fr) == 0.0f)) {
-                rq3.want = true; rq3.any = true; rq3.o = ray.pos; rq3.d = rec.d; rq3.tmax = rec.dist;
-                b = fr;                                                  // finished after stage 3
+                sh = true; sh_o = ray.pos; sh_d = rec.d; sh_tmax = rec.dist;
+                const Mat lm = load_mat(&sc.mats[sc.light_mesh + 1]);
+                f3 contribution = lm.color * fr;
+                if (MEDIUM) contribution = contribution * vexp(splat(sc.fog_sigma_t) * (-1.0f * rec.dist));
+                contribution = contribution * power_heuristic(rec.pdf, bsdf_pdf<MATS>(sc, e, mat));
+                b_vis = contribution / rec.pdf;
             }
         }
-    } else if (kind == K_SCATTER) {
-        if (rq2.want && !r2.found && finish_shadow(sc, rq2.o, rq2.d, rq2.tmax)) {   // base.cl:219-224
-            const Mat lm = load_mat(&sc.mats[sc.light_mesh + 1]);
-            const f3 tr = vexp(splat(sc.fog_sigma_t) * (-1.0f * rec.dist));
-            const f3 contribution = tr * lm.color * splat(fv) * power_heuristic(rec.pdf, fv);
-            a = contribution / rec.pdf;
-        }
-        phase_sample(sc, ray.dir, ps, rng);                              // volumePhaseSample, base.cl:232-260
-        rq3.want = true; rq3.any = false; rq3.o = ms.p; rq3.d = ps.w; rq3.tmax = PT_INF;
-    }
-
-    // ---------------- stage 3
-    const TravRes r3 = wg_traverse<BLOCK>(sc, sm, parity, rq3, stack);
-
-    if (kind == K_SURFACE_MIS) {
-        if (rq3.want && !r3.found && finish_shadow(sc, rq3.o, rq3.d, rq3.tmax)) {
-            const Mat lm = load_mat(&sc.mats[sc.light_mesh + 1]);
-            f3 contribution = lm.color * b;
-            if (MEDIUM) contribution = contribution * vexp(splat(sc.fog_sigma_t) * (-1.0f * rec.dist));
-            contribution = contribution * power_heuristic(rec.pdf, bsdf_pdf<MATS>(sc, e, mat));
-            b = contribution / rec.pdf;
-        } else {
-            b = splat(0.0f);
-        }
+        // ---------------- W3
+        const f3 b = (sh && shadow(sc, sh_o, sh_d, sh_tmax, stk)) ? b_vis : splat(0.0f);
         emission = emission + (a + b) * st.mask;
     } else if (kind == K_SCATTER) {
         Ray sRay;
         sRay.origin = ms.p; sRay.dir = ps.w; sRay.normal = splat(0.0f); sRay.pos = splat(0.0f); sRay.backside = false;
         sRay.t = PT_INF; sRay.time = 0.0f;
+        f3 b = splat(0.0f);
         int mid;
-        const bool hit3 = finish_closest(sc, sRay, r3, mid);
+        const bool hit3 = finish_closest(sc, sRay, r2, mid);
         st.hc.valid = true; st.hc.didHit = hit3; st.hc.backside = sRay.backside; st.hc.t = sRay.t; st.hc.mesh_id = mid;
         st.hc.normal = sRay.normal; st.hc.pos = sRay.pos;
         if (hit3) {
@@ -1218,6 +1135,8 @@ PT_DEV void radiance_segment(const DevScene& sc, WgShared<BLOCK>& sm, unsigned& 
                 b = tr * lm.color * ps.weight * power_heuristic(ps.pdf, direct_pdf_mesh(sc, mid, sRay.dir, ms.p));
             }
         }
+        // ---------------- W3
+        const f3 a = (sh && shadow(sc, sh_o, sh_d, sh_tmax, stk)) ? a_vis : splat(0.0f);
         emission = emission + (a + b) * st.mask;
         ray.origin = ms.p;                                               // pathtracing.cl:58-61
         ray.dir = ps.w;
@@ -1249,7 +1168,7 @@ PT_DEV void radiance_segment(const DevScene& sc, WgShared<BLOCK>& sm, unsigned& 
             (int)st.spec >= sc.max_spec_bounces || (int)st.trans >= sc.max_trans_bounces)
             st.reset = true;                                             // pathtracing.cl:109-115
     }
-    if (live) { st.acc[0] += emission.x; st.acc[1] += emission.y; st.acc[2] += emission.z; st.acc[3] += alpha; }
+    st.acc[0] += emission.x; st.acc[1] += emission.y; st.acc[2] += emission.z; st.acc[3] += alpha;   // main.cl:142
 }
 
 }  // namespace dev

@@ -4,10 +4,12 @@
 //   state_to_rtd / rtd_to_state   80 B/px SoA planes <-> the reference's 112 B RTD records
 //   count_kernel                  sum of samples / segments / frozen pixels (Msamples/s accounting)
 //
-// Launch geometry: 512-thread workgroups = 8 waves = the domain inside which rays that enter the
-// BVH are regrouped into dense waves through LDS (pt_device.h, wg_traverse); each wave owns an 8x8
-// pixel tile, a workgroup a 32x16 tile.  A 1920x1080 frame is 4 080 workgroups >> 256 CUs.
+// Launch geometry: 256-thread workgroups = 4 waves; each wave owns an 8x8 pixel tile (primary rays of
+// one wave walk the same BVH nodes), a workgroup a 16x16 tile; 32 KiB of LDS per workgroup hold the
+// traversal stacks.  A 1920x1080 frame is 8 160 workgroups >> 256 CUs.
 #include <hip/hip_runtime.h>
+
+#include <cstdlib>
 
 #include "pt_device.h"
 #include "pt_launch.h"
@@ -17,24 +19,18 @@ namespace prt {
 using namespace dev;
 
 #ifndef PT_MIN_WAVES
-#define PT_MIN_WAVES 4      // waves per SIMD the register allocator must leave room for (tuning knob)
+#define PT_MIN_WAVES 4      // waves per SIMD the register allocator must leave room for (128 VGPRs)
 #endif
 #ifndef PT_BLOCK
-#define PT_BLOCK 256        // threads per workgroup (with PT_COOPERATIVE: the domain rays are regrouped in)
+#define PT_BLOCK 256        // threads per workgroup
+#endif
+#ifndef PT_LDS_STACK
+#define PT_LDS_STACK 32     // traversal-stack levels kept in LDS ([level][thread]: conflict-free, 32 KiB per workgroup)
 #endif
 
 template <unsigned MATS, bool MEDIUM>
 __global__ __launch_bounds__(PT_BLOCK, PT_MIN_WAVES) void render_kernel(const DevScene sc, const DevCamera cam, const DevState S,
                                                                         const FrameArgs fa, float4* __restrict__ fb) {
-#if PT_COOPERATIVE
-    __shared__ WgShared<PT_BLOCK> sm;
-    if (threadIdx.x < 2) sm.count[threadIdx.x] = 0;
-    __syncthreads();
-#else
-    WgShared<1> sm_unused;
-    auto& sm = reinterpret_cast<WgShared<PT_BLOCK>&>(sm_unused);     // never touched when PT_COOPERATIVE == 0
-#endif
-    unsigned parity = 0;
     // workgroup tile: (PT_BLOCK / 128) x 2 waves of 8x8 pixels
     constexpr int TILE_W = PT_BLOCK / 16, WAVES_X = TILE_W / 8;
     const int tiles_x = (fa.width + TILE_W - 1) / TILE_W;
@@ -42,8 +38,8 @@ __global__ __launch_bounds__(PT_BLOCK, PT_MIN_WAVES) void render_kernel(const De
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int lx = tile_x * TILE_W + (wave % WAVES_X) * 8 + (lane & 7);
     const int ly = tile_y * 16 + (wave / WAVES_X) * 8 + (lane >> 3);
-    const bool valid = lx < fa.width && ly < fa.rows;          // lanes outside the image still take part in the barriers
-    const size_t id = valid ? (size_t)ly * (size_t)fa.width + (size_t)lx : 0;
+    if (lx >= fa.width || ly >= fa.rows) return;                // no barriers in this kernel
+    const size_t id = (size_t)ly * (size_t)fa.width + (size_t)lx;
     const int gx = lx;
     const int gy = fa.row0 + (ly / fa.block_rows * fa.n_parts + fa.part) * fa.block_rows + ly % fa.block_rows;
 
@@ -64,16 +60,11 @@ __global__ __launch_bounds__(PT_BLOCK, PT_MIN_WAVES) void render_kernel(const De
     }
     __shared__ unsigned lds_stack[PT_LDS_STACK * PT_BLOCK];
     unsigned deep_stack[PT_STACK_DEPTH - PT_LDS_STACK];
-    TravStack stack;
-    stack.lds = lds_stack + threadIdx.x; stack.stride = PT_BLOCK; stack.deep = deep_stack;
+    TravStack stk;
+    stk.lds = lds_stack + threadIdx.x; stk.stride = PT_BLOCK; stk.deep = deep_stack; stk.lds_levels = PT_LDS_STACK;
     bool ran = false;
     for (unsigned f = 0; f < fa.n_frames; ++f) {
-        const bool live = valid && !(fa.spp_limit && st.reset && st.samples >= fa.spp_limit);   // frozen = the "N spp" rule
-#if PT_COOPERATIVE
-        if (fa.spp_limit && __syncthreads_or(live) == 0) break;                // the whole workgroup is frozen
-#else
-        if (!__any(live)) break;                                               // the whole wave is frozen
-#endif
+        if (fa.spp_limit && st.reset && st.samples >= fa.spp_limit) break;     // frozen (the "N spp" rule)
         const unsigned frame = fa.first_frame + f;
         const int random0 = fa.seed_pairs[2 * f], random1 = fa.seed_pairs[2 * f + 1];
         Rng rng;                                                               // kernels/main.cl:108-109
@@ -83,7 +74,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_MIN_WAVES) void render_kernel(const De
         ray.origin = st.origin; ray.dir = st.dir;
         ray.normal = splat(0.0f); ray.pos = splat(0.0f);
         ray.t = st.dist; ray.backside = false; ray.time = st.time;
-        if (live && (st.reset || st.samples == 0)) {                           // main.cl:122-136
+        if (st.reset || st.samples == 0) {                                     // main.cl:122-136
             ++st.samples;
             st.total = 0; st.diff = 0; st.spec = 0; st.trans = 0; st.scatters = 0;
             st.wasSpecular = true;
@@ -92,13 +83,11 @@ __global__ __launch_bounds__(PT_BLOCK, PT_MIN_WAVES) void render_kernel(const De
             st.hc.valid = false;
             ray = create_cam_ray(gx, gy, fa.width, fa.full_height, cam, rng);
         }
-        radiance_segment<MATS, MEDIUM, PT_BLOCK>(sc, sm, parity, live, ray, st, rng, stack);   // main.cl:142
-        if (live) {
-            st.origin = ray.origin; st.dir = ray.dir;                          // rayToTemp, main.cl:28:
-            st.time = ray.t;                                                   //   {origin, dir, ray.t, ray.time}
-            st.dist = ray.time;                                                //   -> {origin, dir, time, dist}
-            ran = true;
-        }
+        radiance_segment<MATS, MEDIUM>(sc, ray, st, rng, stk);                 // main.cl:142
+        st.origin = ray.origin; st.dir = ray.dir;                              // rayToTemp, main.cl:28:
+        st.time = ray.t;                                                       //   {origin, dir, ray.t, ray.time}
+        st.dist = ray.time;                                                    //   -> {origin, dir, time, dist}
+        ran = true;
     }
     if (ran) {
         S.q0[id] = make_float4(st.origin.x, st.origin.y, st.origin.z, st.time);
@@ -111,9 +100,9 @@ __global__ __launch_bounds__(PT_BLOCK, PT_MIN_WAVES) void render_kernel(const De
         fb[id] = make_float4(st.acc[0] / ns, st.acc[1] / ns, st.acc[2] / ns, st.acc[3] / ns);
     }
     if (fa.unfinished) {
-        const bool unfinished = valid && !(fa.spp_limit && st.reset && st.samples >= fa.spp_limit);
+        const bool unfinished = !(fa.spp_limit && st.reset && st.samples >= fa.spp_limit);
         const unsigned long long m = __ballot(unfinished);
-        if (m && lane == (int)__builtin_ctzll(m)) atomicAdd(fa.unfinished, (unsigned long long)__popcll(m));
+        if (m && lane == (int)__builtin_ctzll(__ballot(1))) atomicAdd(fa.unfinished, (unsigned long long)__popcll(m));
     }
 }
 
@@ -204,6 +193,8 @@ static void launch_variant(const DevScene& sc, const DevCamera& cam, const DevSt
     hipLaunchKernelGGL((render_kernel<MATS, MEDIUM>), dim3(tiles_x * tiles_y), dim3(PT_BLOCK), 0, stream, sc, cam, S, fa, fb);
 }
 
+// Variant choice = the AOT analogue of the reference's per-scene program build (include/CL/cl_kernel.h):
+// material set (LIGHT|DIFF only, or generic) x global medium.
 const char* launch_render(const DevScene& sc, const DevCamera& cam, const DevState& S, const FrameArgs& fa, float4* fb,
                           hipStream_t stream) {
     constexpr unsigned LD = PRT_MAT_LIGHT | PRT_MAT_DIFF;
