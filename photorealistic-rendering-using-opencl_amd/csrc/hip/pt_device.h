@@ -958,137 +958,164 @@ struct Path {
     bool wasSpecular, reset;
 };
 
-// shadow(), kernels/intersect.cl:94-152: true = unoccluded.  The BVH, sphere and quad tests are
-// independent (no state, no RNG, the any-hit walk never shrinks ray.t), so the boolean does not depend on
-// their order: the 7 primitives are tested first and the tree is only walked when they do not occlude.
-PT_DEV bool shadow(const DevScene& sc, const f3 o, const f3 d, const float tmax, const TravStack& stack) {
-    if (!finish_shadow(sc, o, d, tmax)) return false;
-    TravReq rq;
-    rq.want = true; rq.o = o; rq.d = d; rq.tmax = tmax;
-    return !walk(sc, true, rq, stack).found;
-}
 
 // ---- one segment: kernels/integrators/pathtracing.cl:4-120 + base.cl:31-260 -----------------------------
-// Per lane, in the reference's order, so every RNG draw happens exactly where it does there.  Walks:
-//   W1  closest hit of the path ray (intersect_scene, pathtracing.cl:27) -- skipped when the hit cache
-//       holds it (the previous segment's probe)
-//   W2  closest hit of the BSDF-sampled probe ray (bsdfSample, base.cl:54-57) or of the phase-sampled
-//       probe ray (volumePhaseSample, base.cl:247)
-//   W3  any-hit of the light shadow ray (lightSample base.cl:115, volumeLightSample base.cl:219).  Its
-//       result only selects the radiance added to acc, so for a medium scatter (where the reference walks
-//       it BEFORE the probe) it runs last here; no RNG draw or path state depends on it.
-// MATS: compile-time ACTIVE_MATS (0 = generic); MEDIUM: compile-time GLOBAL_MEDIUM.
-template <unsigned MATS, bool MEDIUM>
-PT_DEV void radiance_segment(const DevScene& sc, Ray& ray, Path& st, Rng& rng, const TravStack& stk) {
-    const unsigned am = active_mats<MATS>(sc);
-    f3 emission = splat(0.0f);
-    float alpha = 1.0f;
-    bool done = false;
+// Written as four PHASES separated by the segment's three BVH walks, in the reference's order, so every
+// RNG draw happens exactly where it does there:
+//   seg_begin      (re)start the path if needed (main.cl:122-136); ask for W1 = closest hit of the path ray
+//                  (intersect_scene, pathtracing.cl:27) unless the hit cache holds it
+//   seg_after_w1   medium event, miss / emitter / surface, BSDF or phase sampling; ask for W2 = closest hit of
+//                  the BSDF-sampled probe ray (bsdfSample, base.cl:54-57) or of the phase-sampled probe ray
+//                  (volumePhaseSample, base.cl:247)
+//   seg_after_w2   MIS term of the probe, light sampling; ask for W3 = any-hit of the light shadow ray
+//                  (lightSample base.cl:115, volumeLightSample base.cl:219).  W3 only selects the radiance that
+//                  is added to acc: no RNG draw or path state depends on it, so for a medium scatter (where the
+//                  reference walks it BEFORE the probe) it is simply asked for last.
+//   seg_finish     radiance into acc, Russian roulette, bounce caps (pathtracing.cl:97-118, main.cl:142)
+// The megakernel runs the phases back to back with the walks inline; the wavefront pipeline suspends a pixel
+// at a walk that really enters the tree and resumes it in a later pass (SegCtx is what survives).
+struct SegCtx {
+    Ray ray;
+    Rng rng;
+    Event e;
+    int mesh_id, kind;
+    bool terminate, surface, done, sh;
+    f3 emission;
+    float alpha;
+    f3 ms_p;                 // medium scatter position
+    LightSample rec;
+    PhaseSample ps;
+    f3 a;                    // surface: probe MIS term; scatter: unused
+    f3 a_vis, b_vis;         // light-sample term if the shadow ray is unoccluded (scatter / surface)
+    f3 sh_o, sh_d;
+    float sh_tmax;
+};
+enum { K_NONE = 0, K_SURFACE_MIS = 1, K_SCATTER = 2 };
 
-    // ---------------- W1
-    int mesh_id = -1;
+PT_DEV void seg_ctx_init(SegCtx& c) {
+    c.e.wi = c.e.wo = splat(0.0f); c.e.weight = splat(1.0f); c.e.pdf = 1.0f; c.e.sampledLobe = 0;
+    c.e.frame.normal = c.e.frame.tangent = c.e.frame.bitangent = splat(0.0f);
+    c.mesh_id = -1; c.kind = K_NONE;
+    c.terminate = c.surface = c.done = c.sh = false;
+    c.emission = splat(0.0f); c.alpha = 1.0f;
+    c.ms_p = splat(0.0f);
+    c.rec.d = splat(0.0f); c.rec.dist = 0.0f; c.rec.pdf = 1.0f;
+    c.ps.w = c.ps.weight = splat(0.0f); c.ps.pdf = 1.0f;
+    c.a = c.a_vis = c.b_vis = splat(0.0f);
+    c.sh_o = c.sh_d = splat(0.0f); c.sh_tmax = 0.0f;
+}
+
+// kernels/main.cl:108-136: seeds, tempToRay, path (re)start.  Returns the W1 request.
+PT_DEV TravReq seg_begin(const DevCamera& cam, SegCtx& c, Path& st, int gx, int gy, int width, int full_height,
+                         unsigned frame, int random0, int random1) {
+    seg_ctx_init(c);
+    c.rng.s0 = (unsigned)gx * frame % 1000u + ((unsigned)random0 * 100u);     // main.cl:108-109
+    c.rng.s1 = (unsigned)gy * frame % 1000u + ((unsigned)random1 * 100u);
+    c.ray.origin = st.origin; c.ray.dir = st.dir;                              // tempToRay, main.cl:27
+    c.ray.normal = splat(0.0f); c.ray.pos = splat(0.0f);
+    c.ray.t = st.dist; c.ray.backside = false; c.ray.time = st.time;
+    if (st.reset || st.samples == 0) {                                         // main.cl:122-136
+        ++st.samples;
+        st.total = 0; st.diff = 0; st.spec = 0; st.trans = 0; st.scatters = 0;
+        st.wasSpecular = true;
+        st.reset = false;
+        st.mask = splat(1.0f);
+        st.hc.valid = false;
+        c.ray = create_cam_ray(gx, gy, width, full_height, cam, c.rng);
+    }
+    TravReq rq;
+    rq.want = !st.hc.valid; rq.o = c.ray.origin; rq.d = c.ray.dir; rq.tmax = PT_INF;
+    return rq;
+}
+
+template <unsigned MATS, bool MEDIUM>
+PT_DEV TravReq seg_after_w1(const DevScene& sc, SegCtx& c, Path& st, const TravRes& r1) {
+    const unsigned am = active_mats<MATS>(sc);
+    Ray& ray = c.ray;
     bool didHit;
     if (st.hc.valid) {
-        didHit = st.hc.didHit; mesh_id = st.hc.mesh_id;
+        didHit = st.hc.didHit; c.mesh_id = st.hc.mesh_id;
         ray.t = st.hc.t; ray.normal = st.hc.normal; ray.pos = st.hc.pos; ray.backside = st.hc.backside;
     } else {
-        TravReq rq;
-        rq.want = true; rq.o = ray.origin; rq.d = ray.dir; rq.tmax = PT_INF;
-        const TravRes r1 = walk(sc, false, rq, stk);
-        didHit = finish_closest(sc, ray, r1, mesh_id);
+        didHit = finish_closest(sc, ray, r1, c.mesh_id);
     }
     st.hc.valid = false;
-    const Mat mat = load_mat((mesh_id + 1) ? &sc.mats[mesh_id + 1] : &sc.mats[sc.n_meshes + 1]);
-
-    enum { K_NONE = 0, K_SURFACE_MIS = 1, K_SCATTER = 2 };
-    int kind = K_NONE;
-    Event e;
-    e.wi = e.wo = splat(0.0f); e.weight = splat(1.0f); e.pdf = 1.0f; e.sampledLobe = 0;
-    e.frame.normal = e.frame.tangent = e.frame.bitangent = splat(0.0f);
-    bool terminate = false, surface = false;
-    MediumSample ms;
-    ms.p = splat(0.0f); ms.weight = splat(1.0f); ms.exited = true;
-    LightSample rec;
-    rec.d = splat(0.0f); rec.dist = 0.0f; rec.pdf = 1.0f;
-    PhaseSample ps;
-    ps.w = ps.weight = splat(0.0f); ps.pdf = 1.0f;
-    bool sh = false;                 // this segment has a shadow ray to decide
-    f3 sh_o = splat(0.0f), sh_d = splat(0.0f);
-    float sh_tmax = 0.0f;
-    f3 a_vis = splat(0.0f);          // scatter: the light-sample term if the shadow ray is unoccluded
-    f3 b_vis = splat(0.0f);          // surface: the same
+    const Mat mat = load_mat((c.mesh_id + 1) ? &sc.mats[c.mesh_id + 1] : &sc.mats[sc.n_meshes + 1]);
     TravReq rq2;
     rq2.want = false; rq2.o = rq2.d = splat(0.0f); rq2.tmax = PT_INF;
-
     bool scattered = false;
     if (MEDIUM) {
-        medium_sample_distance(sc, ms, ray, rng);
+        MediumSample ms;
+        medium_sample_distance(sc, ms, ray, c.rng);
         st.mask = st.mask * ms.weight;
         if (!ms.exited && (int)st.scatters < sc.max_scattering_events) {
             scattered = true;
-            kind = K_SCATTER;
+            c.kind = K_SCATTER;
+            c.ms_p = ms.p;
             st.scatters = (st.scatters + 1u) & 0xffffu;
             st.wasSpecular = false;
             // volumeLightSample, base.cl:194-230 (samples the light from ray.pos, not ms.p: SURVEY s9-Q4)
-            if (sample_light0(sc, ray.pos, rec, rng)) {
-                const float fv = phase_value(sc, ray.dir, rec.d);
+            if (sample_light0(sc, ray.pos, c.rec, c.rng)) {
+                const float fv = phase_value(sc, ray.dir, c.rec.d);
                 const f3 f = splat(fv);
                 if (!(dot(f, f) == 0.0f)) {
-                    sh = true; sh_o = ms.p; sh_d = rec.d; sh_tmax = rec.dist;
+                    c.sh = true; c.sh_o = ms.p; c.sh_d = c.rec.d; c.sh_tmax = c.rec.dist;
                     const Mat lm = load_mat(&sc.mats[sc.light_mesh + 1]);
-                    const f3 tr = vexp(splat(sc.fog_sigma_t) * (-1.0f * rec.dist));
-                    const f3 contribution = tr * lm.color * f * power_heuristic(rec.pdf, fv);
-                    a_vis = contribution / rec.pdf;
+                    const f3 tr = vexp(splat(sc.fog_sigma_t) * (-1.0f * c.rec.dist));
+                    const f3 contribution = tr * lm.color * f * power_heuristic(c.rec.pdf, fv);
+                    c.a_vis = contribution / c.rec.pdf;
                 }
             }
-            phase_sample(sc, ray.dir, ps, rng);                          // volumePhaseSample, base.cl:232-260
-            rq2.want = true; rq2.o = ms.p; rq2.d = ps.w; rq2.tmax = PT_INF;
+            phase_sample(sc, ray.dir, c.ps, c.rng);                      // volumePhaseSample, base.cl:232-260
+            rq2.want = true; rq2.o = ms.p; rq2.d = c.ps.w; rq2.tmax = PT_INF;
         }
     }
     if (!scattered) {
         if (!didHit) {
             st.reset = true;
-            if (sc.alpha_testing) { emission = splat(0.0f); alpha = 0.0f; }
-            else emission = st.mask * env_lookup(sc, ray.dir);
-            done = true;
+            if (sc.alpha_testing) { c.emission = splat(0.0f); c.alpha = 0.0f; }
+            else c.emission = st.mask * env_lookup(sc, ray.dir);
+            c.done = true;
         } else if ((am & PRT_MAT_LIGHT) && (mat.t & PRT_MAT_LIGHT)) {
-            if (st.wasSpecular) emission = emission + mat.color * st.mask;
+            if (st.wasSpecular) c.emission = c.emission + mat.color * st.mask;
             st.reset = true;
-            done = true;
+            c.done = true;
         } else {
-            surface = true;
-            e.frame = make_frame(ray.normal);                           // makeLocalScatterEvent, base.cl:11-14
-            e.wi = to_local(e.frame, -ray.dir);
+            c.surface = true;
+            c.e.frame = make_frame(ray.normal);                         // makeLocalScatterEvent, base.cl:11-14
+            c.e.wi = to_local(c.e.frame, -ray.dir);
             if ((am & PRT_MAT_LIGHT) && (mat.lobes & ~(PRT_LOBE_SPECULAR | PRT_LOBE_FORWARD) & 0xffu)) {
-                kind = K_SURFACE_MIS;                                   // handleSurface, base.cl:168-172
-                if (!bsdf_sample2<MATS>(sc, e, ray, mat, rng)) {        // bsdfSample, base.cl:31-77
-                    terminate = true;
+                c.kind = K_SURFACE_MIS;                                 // handleSurface, base.cl:168-172
+                if (!bsdf_sample2<MATS>(sc, c.e, ray, mat, c.rng)) {    // bsdfSample, base.cl:31-77
+                    c.terminate = true;
                 } else {
                     ray.origin = ray.pos;
-                    ray.dir = to_global(e.frame, e.wo);
+                    ray.dir = to_global(c.e.frame, c.e.wo);
                     rq2.want = true; rq2.o = ray.origin; rq2.d = ray.dir; rq2.tmax = PT_INF;
                 }
             } else {
-                if (!bsdf_sample2<MATS>(sc, e, ray, mat, rng)) {        // base.cl:175-181
+                if (!bsdf_sample2<MATS>(sc, c.e, ray, mat, c.rng)) {    // base.cl:175-181
                     st.reset = true;
-                    done = true;
-                    surface = false;
+                    c.done = true;
+                    c.surface = false;
                 } else {
                     ray.origin = ray.pos;
-                    ray.dir = to_global(e.frame, e.wo);
+                    ray.dir = to_global(c.e.frame, c.e.wo);
                 }
             }
         }
     }
+    return rq2;
+}
 
-    // ---------------- W2
-    TravRes r2;
-    r2.found = false; r2.t = PT_INF; r2.th.u = r2.th.v = r2.th.w = 0.0f; r2.th.slot = 0;
-    if (rq2.want) r2 = walk(sc, false, rq2, stk);
-
-    if (kind == K_SURFACE_MIS) {
-        f3 a = splat(0.0f);
-        if (rq2.want) {                                                  // the probe ray, base.cl:54-75
+// `w2_ran`: W2 was asked for (r2 is its result).  Returns the W3 (shadow, any-hit) request; when the
+// primitives already occlude the shadow ray the request is not made and the light term is dropped.
+template <unsigned MATS, bool MEDIUM>
+PT_DEV TravReq seg_after_w2(const DevScene& sc, SegCtx& c, Path& st, const bool w2_ran, const TravRes& r2) {
+    Ray& ray = c.ray;
+    if (c.kind == K_SURFACE_MIS) {
+        const Mat mat = load_mat((c.mesh_id + 1) ? &sc.mats[c.mesh_id + 1] : &sc.mats[sc.n_meshes + 1]);
+        if (w2_ran) {                                                    // the probe ray, base.cl:54-75
             int mid;
             const bool hit2 = finish_closest(sc, ray, r2, mid);
             st.hc.valid = true; st.hc.didHit = hit2; st.hc.backside = ray.backside; st.hc.t = ray.t; st.hc.mesh_id = mid;
@@ -1097,32 +1124,28 @@ PT_DEV void radiance_segment(const DevScene& sc, Ray& ray, Path& st, Rng& rng, c
                 const unsigned lbits = sc.mats[mid + 1].bits;
                 if (lbits & PRT_MAT_LIGHT) {
                     const Mat lm = load_mat(&sc.mats[mid + 1]);
-                    a = lm.color * e.weight * power_heuristic(e.pdf, direct_pdf_mesh(sc, mid, ray.dir, ray.pos));
-                    if (MEDIUM) a = a * vexp(splat(sc.fog_sigma_t) * (-1.0f * ray.t));
+                    c.a = lm.color * c.e.weight * power_heuristic(c.e.pdf, direct_pdf_mesh(sc, mid, ray.dir, ray.pos));
+                    if (MEDIUM) c.a = c.a * vexp(splat(sc.fog_sigma_t) * (-1.0f * ray.t));
                 }
             }
         }
         // lightSample, base.cl:79-134 (from ray.pos = the probe ray's hit point: SURVEY s9-Q4)
-        if (sample_light0(sc, ray.pos, rec, rng)) {
-            e.wo = to_local(e.frame, rec.d);
-            const f3 fr = bsdf_eval2<MATS>(sc, e, mat);
+        if (sample_light0(sc, ray.pos, c.rec, c.rng)) {
+            c.e.wo = to_local(c.e.frame, c.rec.d);
+            const f3 fr = bsdf_eval2<MATS>(sc, c.e, mat);
             if (!(dot(fr, fr) == 0.0f)) {
-                sh = true; sh_o = ray.pos; sh_d = rec.d; sh_tmax = rec.dist;
+                c.sh = true; c.sh_o = ray.pos; c.sh_d = c.rec.d; c.sh_tmax = c.rec.dist;
                 const Mat lm = load_mat(&sc.mats[sc.light_mesh + 1]);
                 f3 contribution = lm.color * fr;
-                if (MEDIUM) contribution = contribution * vexp(splat(sc.fog_sigma_t) * (-1.0f * rec.dist));
-                contribution = contribution * power_heuristic(rec.pdf, bsdf_pdf<MATS>(sc, e, mat));
-                b_vis = contribution / rec.pdf;
+                if (MEDIUM) contribution = contribution * vexp(splat(sc.fog_sigma_t) * (-1.0f * c.rec.dist));
+                contribution = contribution * power_heuristic(c.rec.pdf, bsdf_pdf<MATS>(sc, c.e, mat));
+                c.b_vis = contribution / c.rec.pdf;
             }
         }
-        // ---------------- W3
-        const f3 b = (sh && shadow(sc, sh_o, sh_d, sh_tmax, stk)) ? b_vis : splat(0.0f);
-        emission = emission + (a + b) * st.mask;
-    } else if (kind == K_SCATTER) {
+    } else if (c.kind == K_SCATTER) {
         Ray sRay;
-        sRay.origin = ms.p; sRay.dir = ps.w; sRay.normal = splat(0.0f); sRay.pos = splat(0.0f); sRay.backside = false;
+        sRay.origin = c.ms_p; sRay.dir = c.ps.w; sRay.normal = splat(0.0f); sRay.pos = splat(0.0f); sRay.backside = false;
         sRay.t = PT_INF; sRay.time = 0.0f;
-        f3 b = splat(0.0f);
         int mid;
         const bool hit3 = finish_closest(sc, sRay, r2, mid);
         st.hc.valid = true; st.hc.didHit = hit3; st.hc.backside = sRay.backside; st.hc.t = sRay.t; st.hc.mesh_id = mid;
@@ -1132,43 +1155,66 @@ PT_DEV void radiance_segment(const DevScene& sc, Ray& ray, Path& st, Rng& rng, c
             if (lbits & PRT_MAT_LIGHT) {
                 const Mat lm = load_mat(&sc.mats[mid + 1]);
                 const f3 tr = vexp(splat(sc.fog_sigma_t) * (-1.0f * sRay.t));
-                b = tr * lm.color * ps.weight * power_heuristic(ps.pdf, direct_pdf_mesh(sc, mid, sRay.dir, ms.p));
+                c.a = tr * lm.color * c.ps.weight * power_heuristic(c.ps.pdf, direct_pdf_mesh(sc, mid, sRay.dir, c.ms_p));   // "b" of base.cl:259
             }
         }
-        // ---------------- W3
-        const f3 a = (sh && shadow(sc, sh_o, sh_d, sh_tmax, stk)) ? a_vis : splat(0.0f);
-        emission = emission + (a + b) * st.mask;
-        ray.origin = ms.p;                                               // pathtracing.cl:58-61
-        ray.dir = ps.w;
-        st.mask = st.mask * ps.weight;
     }
-    if (surface && !done) {                                              // handleSurface tail, base.cl:183-191
+    TravReq rq3;
+    rq3.want = false; rq3.o = c.sh_o; rq3.d = c.sh_d; rq3.tmax = c.sh_tmax;
+    // shadow(), intersect.cl:94-152: BVH, sphere and quad tests are independent and the any-hit walk never
+    // shrinks ray.t, so the boolean does not depend on their order: the 7 primitives first.
+    if (c.sh) {
+        if (finish_shadow(sc, c.sh_o, c.sh_d, c.sh_tmax)) rq3.want = true;
+        else c.sh = false;                                               // occluded by a primitive
+    }
+    return rq3;
+}
+
+// `occluded`: result of W3 (ignored unless c.sh)
+PT_DEV void seg_finish(const DevScene& sc, SegCtx& c, Path& st, const bool occluded) {
+    Ray& ray = c.ray;
+    const bool lit = c.sh && !occluded;
+    if (c.kind == K_SURFACE_MIS) {
+        const f3 b = lit ? c.b_vis : splat(0.0f);
+        c.emission = c.emission + (c.a + b) * st.mask;                   // base.cl:170-171
+    } else if (c.kind == K_SCATTER) {
+        const f3 a = lit ? c.a_vis : splat(0.0f);
+        c.emission = c.emission + (a + c.a) * st.mask;                   // pathtracing.cl:52-56
+        ray.origin = c.ms_p;                                             // pathtracing.cl:58-61
+        ray.dir = c.ps.w;
+        st.mask = st.mask * c.ps.weight;
+    }
+    if (c.surface && !c.done) {                                          // handleSurface tail, base.cl:183-191
+        const Event& e = c.e;
         st.wasSpecular = (e.sampledLobe & PRT_LOBE_SPECULAR) != 0;
         st.mask = st.mask * e.weight;
         st.diff = (st.diff + ((e.sampledLobe & (PRT_LOBE_DIFFUSE_R | PRT_LOBE_GLOSSY_R)) != 0)) & 0xffffu;
         st.spec = (st.spec + ((e.sampledLobe & PRT_LOBE_SPECULAR_R) != 0)) & 0xffffu;
         st.trans = (st.trans + ((e.sampledLobe & PRT_LOBE_TRANSMISSIVE) != 0)) & 0xffffu;
-        if (terminate) {
+        if (c.terminate) {
             st.reset = true;
-            done = true;
+            c.done = true;
         } else {
             st.scatters = 0;                                             // pathtracing.cl:93-94
             ++st.total;
         }
     }
-    if (!done) {
+    if (!c.done) {
         const float roulettePdf = fmax3(st.mask);                        // pathtracing.cl:97-106
         if (st.total > 2 && roulettePdf < 0.1f) {
-            if (next1D(rng) < roulettePdf) st.mask = st.mask / roulettePdf;
-            else { st.reset = true; done = true; }
+            if (next1D(c.rng) < roulettePdf) st.mask = st.mask / roulettePdf;
+            else { st.reset = true; c.done = true; }
         }
     }
-    if (!done) {
+    if (!c.done) {
         if (st.total >= (unsigned)sc.max_bounces || (int)st.diff >= sc.max_diff_bounces ||
             (int)st.spec >= sc.max_spec_bounces || (int)st.trans >= sc.max_trans_bounces)
             st.reset = true;                                             // pathtracing.cl:109-115
     }
-    st.acc[0] += emission.x; st.acc[1] += emission.y; st.acc[2] += emission.z; st.acc[3] += alpha;   // main.cl:142
+    st.acc[0] += c.emission.x; st.acc[1] += c.emission.y; st.acc[2] += c.emission.z; st.acc[3] += c.alpha;   // main.cl:142
+    st.origin = ray.origin; st.dir = ray.dir;                            // rayToTemp, main.cl:28:
+    st.time = ray.t;                                                     //   {origin, dir, ray.t, ray.time}
+    st.dist = ray.time;                                                  //   -> {origin, dir, time, dist}
 }
 
 }  // namespace dev

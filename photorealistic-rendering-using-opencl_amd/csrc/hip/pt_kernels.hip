@@ -65,28 +65,17 @@ __global__ __launch_bounds__(PT_BLOCK, PT_MIN_WAVES) void render_kernel(const De
     bool ran = false;
     for (unsigned f = 0; f < fa.n_frames; ++f) {
         if (fa.spp_limit && st.reset && st.samples >= fa.spp_limit) break;     // frozen (the "N spp" rule)
-        const unsigned frame = fa.first_frame + f;
-        const int random0 = fa.seed_pairs[2 * f], random1 = fa.seed_pairs[2 * f + 1];
-        Rng rng;                                                               // kernels/main.cl:108-109
-        rng.s0 = (unsigned)gx * frame % 1000u + ((unsigned)random0 * 100u);
-        rng.s1 = (unsigned)gy * frame % 1000u + ((unsigned)random1 * 100u);
-        Ray ray;                                                               // tempToRay, main.cl:27
-        ray.origin = st.origin; ray.dir = st.dir;
-        ray.normal = splat(0.0f); ray.pos = splat(0.0f);
-        ray.t = st.dist; ray.backside = false; ray.time = st.time;
-        if (st.reset || st.samples == 0) {                                     // main.cl:122-136
-            ++st.samples;
-            st.total = 0; st.diff = 0; st.spec = 0; st.trans = 0; st.scatters = 0;
-            st.wasSpecular = true;
-            st.reset = false;
-            st.mask = splat(1.0f);
-            st.hc.valid = false;
-            ray = create_cam_ray(gx, gy, fa.width, fa.full_height, cam, rng);
-        }
-        radiance_segment<MATS, MEDIUM>(sc, ray, st, rng, stk);                 // main.cl:142
-        st.origin = ray.origin; st.dir = ray.dir;                              // rayToTemp, main.cl:28:
-        st.time = ray.t;                                                       //   {origin, dir, ray.t, ray.time}
-        st.dist = ray.time;                                                    //   -> {origin, dir, time, dist}
+        SegCtx c;
+        TravRes none;
+        none.found = false; none.t = PT_INF; none.th.u = none.th.v = none.th.w = 0.0f; none.th.slot = 0;
+        const TravReq rq1 = seg_begin(cam, c, st, gx, gy, fa.width, fa.full_height, fa.first_frame + f,
+                                      fa.seed_pairs[2 * f], fa.seed_pairs[2 * f + 1]);
+        const TravRes r1 = rq1.want ? walk(sc, false, rq1, stk) : none;
+        const TravReq rq2 = seg_after_w1<MATS, MEDIUM>(sc, c, st, r1);
+        const TravRes r2 = rq2.want ? walk(sc, false, rq2, stk) : none;
+        const TravReq rq3 = seg_after_w2<MATS, MEDIUM>(sc, c, st, rq2.want, r2);
+        const bool occluded = rq3.want ? walk(sc, true, rq3, stk).found : false;
+        seg_finish(sc, c, st, occluded);
         ran = true;
     }
     if (ran) {
