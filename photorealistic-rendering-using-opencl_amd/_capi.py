@@ -81,6 +81,7 @@ PRT_API = [
     ("prt_reset", C.c_int, [C.c_void_p]),
     ("prt_render_frames", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     ("prt_render_spp", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]),
+    ("prt_set_pipeline", C.c_int, [C.c_void_p, C.c_int]),
     ("prt_synchronize", C.c_int, [C.c_void_p]),
     ("prt_read_framebuffer", C.c_int, [C.c_void_p, C.c_void_p]),
     ("prt_copy_framebuffer_to_device", C.c_int, [C.c_void_p, C.c_void_p]),

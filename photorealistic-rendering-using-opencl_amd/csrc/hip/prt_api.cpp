@@ -39,6 +39,10 @@ struct prt_ctx {
     float4* fb = nullptr;
     int32_t* d_seeds = nullptr; size_t seeds_cap = 0;
     unsigned long long* d_counters = nullptr;     // [0] unfinished, [1..3] count_kernel
+    // wavefront pipeline (optional)
+    int pipeline = 0;                              // 0 = megakernel, 1 = wavefront
+    DevWave wv{};
+    bool wv_allocated = false;
     prt_stats stats{};
     std::string err;
     const char* variant = "";
@@ -81,6 +85,7 @@ extern "C" int prt_create(int device, const prt_config* cfg, prt_ctx** out) {
         return PRT_ERR_HIP;
     }
     c->stream = c->own_stream;
+    if (const char* e = std::getenv("PRT_PIPELINE")) c->pipeline = (std::strcmp(e, "wavefront") == 0 || std::strcmp(e, "1") == 0) ? 1 : 0;
     *out = c;
     return PRT_OK;
 }
@@ -94,6 +99,32 @@ static void free_frame(prt_ctx* c) {
     p = c->S.q4; free_dev(p); c->S.q4 = nullptr;
     p = c->fb; free_dev(p); c->fb = nullptr;
 }
+static void free_wave(prt_ctx* c) {
+    void* p;
+    p = c->wv.hc0; free_dev(p); p = c->wv.hc1; free_dev(p); p = c->wv.prog; free_dev(p); p = c->wv.ctx; free_dev(p);
+    p = c->wv.ray_o; free_dev(p); p = c->wv.ray_d; free_dev(p); p = c->wv.res0; free_dev(p); p = c->wv.res1; free_dev(p);
+    p = c->wv.qcount; free_dev(p);
+    c->wv = DevWave{};
+    c->wv_allocated = false;
+}
+static int alloc_wave(prt_ctx* c) {
+    if (c->wv_allocated) return PRT_OK;
+    const size_t n = c->npix;
+    DevWave& w = c->wv;
+    w.npix = n;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&w.hc0), n * 16));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&w.hc1), n * 16));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&w.prog), n * 16));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&w.ctx), n * 16 * PRT_WF_CTX_PLANES));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&w.ray_o), n * 16));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&w.ray_d), n * 16));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&w.res0), n * 16));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&w.res1), n * 4));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&w.qcount), 2 * sizeof(unsigned)));
+    c->wv_allocated = true;
+    return PRT_OK;
+}
+
 static void free_scene(prt_ctx* c) {
     free_dev(c->d_pairs); free_dev(c->d_tri_geom); free_dev(c->d_tri_nrm);
     free_dev(c->d_spheres); free_dev(c->d_quads); free_dev(c->d_mats);
@@ -104,6 +135,7 @@ extern "C" void prt_destroy(prt_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     free_frame(c);
+    free_wave(c);
     free_scene(c);
     free_dev(c->d_env);
     void* p = c->d_seeds; free_dev(p);
@@ -332,6 +364,7 @@ static int alloc_frame(prt_ctx* c, int width, int full_height, int row0, int row
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     free_frame(c);
+    free_wave(c);
     c->width = width; c->full_height = full_height; c->row0 = row0; c->rows = rows;
     c->npix = (size_t)width * (size_t)rows;
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->S.q0), c->npix * 16));
@@ -397,6 +430,40 @@ static FrameArgs frame_args(prt_ctx* c, uint32_t first_frame, uint32_t n, const 
     return fa;
 }
 
+// Wavefront pipeline: passes of (shade, traverse) until every pixel has done its n_frames segments (or froze).
+static int render_wavefront(prt_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t spp, uint32_t* frames_used) {
+    int rc = alloc_wave(c);
+    if (rc) return rc;
+    const DevWave& w = c->wv;
+    // every pixel starts the call at a segment boundary with an empty hit cache
+    HIPCHK(c, hipMemsetAsync(w.prog, 0, c->npix * 16, c->stream));
+    HIPCHK(c, hipMemsetAsync(w.hc1, 0, c->npix * 16, c->stream));
+    HIPCHK(c, hipMemsetAsync(w.qcount, 0, 2 * sizeof(unsigned), c->stream));
+    const unsigned trav_blocks = 2048;                      // 256 CUs x 8 workgroups of 4 waves = 8 waves/SIMD, grid-stride
+    const unsigned batch = 16;
+    const unsigned long long max_passes = 4ull * n_frames + 8;
+    unsigned long long unfinished = 1, pass = 0;
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    while (unfinished && pass < max_passes) {
+        for (unsigned b = 0; b < batch; ++b, ++pass) {
+            const bool last = (b + 1 == batch);
+            if (last) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, sizeof(unsigned long long), c->stream));
+            FrameArgs fa = frame_args(c, first_frame, n_frames, c->d_seeds, spp, last);
+            launch_wf_pass(c->sc, c->cam, c->S, w, fa, c->fb, (unsigned)pass, trav_blocks, c->stream);
+            c->stats.launches += 2;
+        }
+        HIPCHK(c, hipMemcpyAsync(&unfinished, c->d_counters, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    c->timing_pending = true;
+    c->variant = "wavefront";
+    if (frames_used) *frames_used = (uint32_t)pass;
+    if (unfinished) return fail(c, PRT_ERR_NOT_READY, "wavefront: pass limit reached before every pixel finished");
+    return PRT_OK;
+}
+
 extern "C" int prt_render_frames(prt_ctx* c, uint32_t first_frame, uint32_t n_frames, const int32_t* seed_pairs) {
     CTX_CHECK(c);
     int rc = ready(c, "prt_render_frames");
@@ -406,6 +473,11 @@ extern "C" int prt_render_frames(prt_ctx* c, uint32_t first_frame, uint32_t n_fr
     c->stats.launches = 0; c->stats.frames = 0; c->stats.kernel_ms = 0.0;
     if (!n_frames) return PRT_OK;
     if ((rc = ensure_seeds(c, seed_pairs, n_frames))) return rc;
+    if (c->pipeline == 1) {
+        rc = render_wavefront(c, first_frame, n_frames, 0, nullptr);
+        c->stats.frames = n_frames;
+        return rc;
+    }
     const unsigned step = frames_per_launch();
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     for (uint32_t f = 0; f < n_frames; f += step) {
@@ -428,6 +500,11 @@ extern "C" int prt_render_spp(prt_ctx* c, uint32_t spp, uint32_t max_frames, con
     HIPCHK(c, hipSetDevice(c->device));
     c->stats.launches = 0; c->stats.frames = 0; c->stats.kernel_ms = 0.0;
     if ((rc = ensure_seeds(c, seed_pairs, max_frames))) return rc;
+    if (c->pipeline == 1) {
+        rc = render_wavefront(c, 1, max_frames, spp, frames_used);
+        c->stats.frames = max_frames;
+        return rc;
+    }
     const unsigned step = frames_per_launch();
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     uint32_t f = 0;
@@ -447,6 +524,13 @@ extern "C" int prt_render_spp(prt_ctx* c, uint32_t spp, uint32_t max_frames, con
     c->stats.frames = f;
     if (frames_used) *frames_used = f;
     if (unfinished) return fail(c, PRT_ERR_NOT_READY, "prt_render_spp: max_frames reached before every pixel finished");
+    return PRT_OK;
+}
+
+extern "C" int prt_set_pipeline(prt_ctx* c, int pipeline) {
+    CTX_CHECK(c);
+    if (pipeline != 0 && pipeline != 1) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_set_pipeline: 0 = megakernel, 1 = wavefront");
+    c->pipeline = pipeline;
     return PRT_OK;
 }
 

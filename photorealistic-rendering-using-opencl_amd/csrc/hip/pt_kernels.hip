@@ -95,6 +95,262 @@ __global__ __launch_bounds__(PT_BLOCK, PT_MIN_WAVES) void render_kernel(const De
     }
 }
 
+// ======================================================================================================
+// Wavefront pipeline: wf_shade_kernel (all pixels: resume or start a segment, run phases until a walk that
+// really enters the tree, then suspend) + wf_trav_kernel (dense waves walk the compacted ray queue, 64 VGPRs
+// -> 8 waves/SIMD to hide the walk's latency chain).  One pass = one launch of each.  Pixels are independent
+// (seeds depend on the pixel's own frame number), so they are allowed to drift apart: a segment with d deep
+// walks simply takes d + 1 passes.
+// ======================================================================================================
+// What a suspended pixel needs when its walk has been answered depends on where it stopped, so each of
+// the three suspension points has its own (small) record: 3 float4 while waiting for W1 (a fresh ray),
+// 6 (surface) / 11 (medium scatter) for W2, 5 / 8 for W3.  Everything else of SegCtx is at its initial
+// value or dead at that point; the tangent frame is rebuilt from its normal (header.cl:179-192 is pure).
+PT_DEV float4 pk(f3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
+PT_DEV float4 pku(f3 v, unsigned w) { return make_float4(v.x, v.y, v.z, prt_u2f(w)); }
+PT_DEV f3 xyz(float4 v) { return F3(v.x, v.y, v.z); }
+#define CTXP(j) wv.ctx[(size_t)(j) * wv.npix + id]
+PT_DEV unsigned ctx_bits(const SegCtx& c, bool w2_ran) {
+    return (c.e.sampledLobe & 0xffu) | ((unsigned)c.kind << 8) | (c.terminate ? 1u << 16 : 0u) | (c.surface ? 1u << 17 : 0u) |
+           (c.done ? 1u << 18 : 0u) | (c.sh ? 1u << 19 : 0u) | (w2_ran ? 1u << 20 : 0u);
+}
+PT_DEV void ctx_unbits(unsigned b, SegCtx& c, bool& w2_ran) {
+    c.e.sampledLobe = b & 0xffu; c.kind = (int)((b >> 8) & 0xffu);
+    c.terminate = (b >> 16) & 1u; c.surface = (b >> 17) & 1u; c.done = (b >> 18) & 1u; c.sh = (b >> 19) & 1u; w2_ran = (b >> 20) & 1u;
+}
+PT_DEV void ctx_store1(const DevWave& wv, size_t id, const SegCtx& c) {
+    CTXP(0) = pk(c.ray.origin, c.ray.time);
+    CTXP(1) = pku(c.ray.dir, c.rng.s0);
+    CTXP(2) = make_float4(prt_u2f(c.rng.s1), 0.f, 0.f, 0.f);
+}
+PT_DEV void ctx_load1(const DevWave& wv, size_t id, SegCtx& c) {
+    seg_ctx_init(c);
+    const float4 p0 = CTXP(0), p1 = CTXP(1), p2 = CTXP(2);
+    c.ray.origin = xyz(p0); c.ray.time = p0.w;
+    c.ray.dir = xyz(p1); c.rng.s0 = prt_f2u(p1.w); c.rng.s1 = prt_f2u(p2.x);
+    c.ray.normal = splat(0.0f); c.ray.pos = splat(0.0f); c.ray.t = 0.0f; c.ray.backside = false;
+}
+template <bool MEDIUM>
+PT_DEV void ctx_store2(const DevWave& wv, size_t id, const SegCtx& c, bool w2_ran) {
+    CTXP(0) = pk(c.ray.origin, c.ray.time);
+    CTXP(1) = pku(c.ray.dir, c.rng.s0);
+    CTXP(2) = pku(c.ray.normal, c.rng.s1);
+    CTXP(3) = pk(c.e.wi, c.e.pdf);
+    CTXP(4) = pku(c.e.weight, ctx_bits(c, w2_ran));
+    CTXP(5) = pku(c.e.frame.normal, (unsigned)(c.mesh_id + 1));
+    if (MEDIUM && c.kind == K_SCATTER) {
+        CTXP(6) = pk(c.ms_p, c.ps.pdf);
+        CTXP(7) = pk(c.ps.w, c.sh_tmax);
+        CTXP(8) = pk(c.ps.weight, c.ray.t);          // a scatter keeps the path ray's t (it becomes RTD.time)
+        CTXP(9) = pk(c.a_vis, 0.f);
+        CTXP(10) = pk(c.sh_d, 0.f);
+    }
+}
+template <bool MEDIUM>
+PT_DEV void ctx_load2(const DevWave& wv, size_t id, SegCtx& c, bool& w2_ran) {
+    seg_ctx_init(c);
+    const float4 p0 = CTXP(0), p1 = CTXP(1), p2 = CTXP(2), p3 = CTXP(3), p4 = CTXP(4), p5 = CTXP(5);
+    c.ray.origin = xyz(p0); c.ray.time = p0.w;
+    c.ray.dir = xyz(p1); c.rng.s0 = prt_f2u(p1.w);
+    c.ray.normal = xyz(p2); c.rng.s1 = prt_f2u(p2.w);
+    c.ray.pos = splat(0.0f); c.ray.t = 0.0f; c.ray.backside = false;
+    c.e.wi = xyz(p3); c.e.pdf = p3.w;
+    c.e.weight = xyz(p4); ctx_unbits(prt_f2u(p4.w), c, w2_ran);
+    c.e.frame = make_frame(xyz(p5)); c.mesh_id = (int)prt_f2u(p5.w) - 1;
+    if (MEDIUM && c.kind == K_SCATTER) {
+        const float4 p6 = CTXP(6), p7 = CTXP(7), p8 = CTXP(8), p9 = CTXP(9), p10 = CTXP(10);
+        c.ms_p = xyz(p6); c.ps.pdf = p6.w;
+        c.ps.w = xyz(p7); c.sh_tmax = p7.w;
+        c.ps.weight = xyz(p8); c.ray.t = p8.w;
+        c.a_vis = xyz(p9);
+        c.sh_d = xyz(p10); c.sh_o = c.ms_p;
+    }
+}
+template <bool MEDIUM>
+PT_DEV void ctx_store3(const DevWave& wv, size_t id, const SegCtx& c) {
+    CTXP(0) = pk(c.ray.origin, c.ray.time);
+    CTXP(1) = pk(c.ray.dir, c.ray.t);
+    CTXP(2) = pku(c.e.weight, ctx_bits(c, false));
+    CTXP(3) = pku(c.a, c.rng.s0);
+    CTXP(4) = pku((MEDIUM && c.kind == K_SCATTER) ? c.a_vis : c.b_vis, c.rng.s1);
+    if (MEDIUM && c.kind == K_SCATTER) {
+        CTXP(5) = pk(c.ms_p, c.alpha);
+        CTXP(6) = pk(c.ps.w, 0.f);
+        CTXP(7) = pk(c.ps.weight, 0.f);
+    }
+}
+template <bool MEDIUM>
+PT_DEV void ctx_load3(const DevWave& wv, size_t id, SegCtx& c) {
+    seg_ctx_init(c);
+    bool unused;
+    const float4 p0 = CTXP(0), p1 = CTXP(1), p2 = CTXP(2), p3 = CTXP(3), p4 = CTXP(4);
+    c.ray.origin = xyz(p0); c.ray.time = p0.w;
+    c.ray.dir = xyz(p1); c.ray.t = p1.w;
+    c.e.weight = xyz(p2); ctx_unbits(prt_f2u(p2.w), c, unused);
+    c.a = xyz(p3); c.rng.s0 = prt_f2u(p3.w);
+    c.rng.s1 = prt_f2u(p4.w);
+    if (MEDIUM && c.kind == K_SCATTER) {
+        c.a_vis = xyz(p4);
+        const float4 p5 = CTXP(5), p6 = CTXP(6), p7 = CTXP(7);
+        c.ms_p = xyz(p5);
+        c.ps.w = xyz(p6);
+        c.ps.weight = xyz(p7);
+    } else {
+        c.b_vis = xyz(p4);
+    }
+}
+#undef CTXP
+
+// does the walk of `rq` get past its first step?  (bvh.cl:144-157 at node 0 -- the same test the walk starts with)
+PT_DEV bool walk_is_deep(const DevScene& sc, const TravReq& rq) {
+    if (sc.root_is_leaf) return sc.root_leaf_count != 0;
+    Ray ray;
+    ray.origin = rq.o; ray.dir = rq.d;
+    const PairTest pt = test_pair(load_pair(sc.pairs, 0u), ray_pre(ray), rq.tmax);
+    return pt.go0 || pt.go1;
+}
+
+template <unsigned MATS, bool MEDIUM>
+#ifndef PT_SHADE_WAVES
+#define PT_SHADE_WAVES 4
+#endif
+__global__ __launch_bounds__(256, PT_SHADE_WAVES) void wf_shade_kernel(const DevScene sc, const DevCamera cam, const DevState S, const DevWave wv,
+                                                       const FrameArgs fa, float4* __restrict__ fb, const unsigned pass) {
+    constexpr int TILE_W = 16, WAVES_X = 2;
+    const int tiles_x = (fa.width + TILE_W - 1) / TILE_W;
+    const int tile_x = (int)(blockIdx.x % (unsigned)tiles_x), tile_y = (int)(blockIdx.x / (unsigned)tiles_x);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lx = tile_x * TILE_W + (wave % WAVES_X) * 8 + (lane & 7);
+    const int ly = tile_y * 16 + (wave / WAVES_X) * 8 + (lane >> 3);
+    if (lx >= fa.width || ly >= fa.rows) return;
+    const size_t id = (size_t)ly * (size_t)fa.width + (size_t)lx;
+    const int gx = lx;
+    const int gy = fa.row0 + (ly / fa.block_rows * fa.n_parts + fa.part) * fa.block_rows + ly % fa.block_rows;
+
+    uint4 prog = wv.prog[id];
+    const uint4 e4 = S.q4[id];
+    bool active = prog.x < fa.n_frames;
+    if (active && prog.y == 0 && fa.spp_limit && (e4.w & 2u) && e4.x >= fa.spp_limit) active = false;     // frozen
+    bool enqueue = false;
+    TravReq rq;
+    rq.want = false; rq.o = rq.d = splat(0.0f); rq.tmax = PT_INF;
+    bool rq_any = false;
+    if (active) {
+        Path st;
+        {
+            const float4 a = S.q0[id], b = S.q1[id], c = S.q2[id], d = S.q3[id];
+            st.origin = F3(a.x, a.y, a.z); st.time = a.w;
+            st.dir = F3(b.x, b.y, b.z); st.dist = b.w;
+            st.mask = F3(c.x, c.y, c.z); st.total = prt_f2u(c.w);
+            st.acc[0] = d.x; st.acc[1] = d.y; st.acc[2] = d.z; st.acc[3] = d.w;
+            st.samples = e4.x;
+            st.diff = e4.y & 0xffffu; st.spec = e4.y >> 16;
+            st.trans = e4.z & 0xffffu; st.scatters = e4.z >> 16;
+            st.wasSpecular = (e4.w & 1u) != 0; st.reset = (e4.w & 2u) != 0;
+            const float4 h0 = wv.hc0[id], h1 = wv.hc1[id];
+            const unsigned hb = prt_f2u(h1.w);
+            st.hc.valid = (hb & 1u) != 0; st.hc.didHit = (hb & 2u) != 0; st.hc.backside = (hb & 4u) != 0;
+            st.hc.mesh_id = (int)(hb >> 8) - 1;
+            st.hc.t = h0.x; st.hc.normal = F3(h0.y, h0.z, h0.w); st.hc.pos = F3(h1.x, h1.y, h1.z);
+        }
+        SegCtx c;
+        TravRes res;
+        res.found = false; res.t = PT_INF; res.th.u = res.th.v = res.th.w = 0.0f; res.th.slot = 0;
+        bool w2_ran = false;
+        unsigned stage = prog.y;                                // 0 = segment boundary, k = the answer of W_k is in res0/res1
+        if (stage != 0) {
+            const float4 r = wv.res0[id];
+            const unsigned r1 = wv.res1[id];
+            res.found = (r1 >> 31) != 0; res.t = r.x; res.th.u = r.y; res.th.v = r.z; res.th.w = r.w; res.th.slot = r1 & 0x7fffffffu;
+            if (stage == 1) ctx_load1(wv, id, c);
+            else if (stage == 2) ctx_load2<MEDIUM>(wv, id, c, w2_ran);
+            else ctx_load3<MEDIUM>(wv, id, c);
+        }
+        // straight-line phases; `enqueue` = suspended at a walk that really enters the tree
+        auto trivial = [&](const TravReq& q) {                  // answer of a walk that is not needed / ends at its first step
+            res.found = false; res.t = q.tmax; res.th.u = res.th.v = res.th.w = 0.0f; res.th.slot = 0;
+        };
+        if (stage == 0) {
+            const unsigned f = prog.x;
+            rq = seg_begin(cam, c, st, gx, gy, fa.width, fa.full_height, fa.first_frame + f, fa.seed_pairs[2 * f], fa.seed_pairs[2 * f + 1]);
+            rq_any = false; stage = 1;
+            if (rq.want && walk_is_deep(sc, rq)) { enqueue = true; ctx_store1(wv, id, c); } else trivial(rq);
+        }
+        if (stage == 1 && !enqueue) {
+            rq = seg_after_w1<MATS, MEDIUM>(sc, c, st, res);
+            w2_ran = rq.want; rq_any = false; stage = 2;
+            if (rq.want && walk_is_deep(sc, rq)) { enqueue = true; ctx_store2<MEDIUM>(wv, id, c, w2_ran); } else trivial(rq);
+        }
+        if (stage == 2 && !enqueue) {
+            rq = seg_after_w2<MATS, MEDIUM>(sc, c, st, w2_ran, res);
+            rq_any = true; stage = 3;
+            if (rq.want && walk_is_deep(sc, rq)) { enqueue = true; ctx_store3<MEDIUM>(wv, id, c); } else trivial(rq);
+        }
+        bool finished_segment = false;
+        if (stage == 3 && !enqueue) {
+            seg_finish(sc, c, st, res.found);
+            finished_segment = true;
+        }
+        if (finished_segment) { prog.x += 1; prog.y = 0; }
+        else prog.y = stage;
+        // state back to HBM
+        S.q0[id] = make_float4(st.origin.x, st.origin.y, st.origin.z, st.time);
+        S.q1[id] = make_float4(st.dir.x, st.dir.y, st.dir.z, st.dist);
+        S.q2[id] = make_float4(st.mask.x, st.mask.y, st.mask.z, prt_u2f(st.total));
+        S.q3[id] = make_float4(st.acc[0], st.acc[1], st.acc[2], st.acc[3]);
+        const unsigned flags = (st.wasSpecular ? 1u : 0u) | (st.reset ? 2u : 0u);
+        S.q4[id] = make_uint4(st.samples, (st.diff & 0xffffu) | (st.spec << 16), (st.trans & 0xffffu) | (st.scatters << 16), flags);
+        wv.hc0[id] = make_float4(st.hc.t, st.hc.normal.x, st.hc.normal.y, st.hc.normal.z);
+        wv.hc1[id] = make_float4(st.hc.pos.x, st.hc.pos.y, st.hc.pos.z,
+                                 prt_u2f((st.hc.valid ? 1u : 0u) | (st.hc.didHit ? 2u : 0u) | (st.hc.backside ? 4u : 0u) | ((unsigned)(st.hc.mesh_id + 1) << 8)));
+        wv.prog[id] = prog;
+        if (finished_segment) {
+            const float ns = (float)st.samples;                    // write_imagef, main.cl:159
+            fb[id] = make_float4(st.acc[0] / ns, st.acc[1] / ns, st.acc[2] / ns, st.acc[3] / ns);
+            active = prog.x < fa.n_frames && !(fa.spp_limit && st.reset && st.samples >= fa.spp_limit);
+        }
+    }
+    // compact the suspended rays of this wave into the queue: ballot + one atomic per wave
+    const unsigned long long m = __ballot(enqueue);
+    if (m) {
+        unsigned base = 0;
+        const int leader = (int)__builtin_ctzll(m);
+        if (lane == leader) base = atomicAdd(&wv.qcount[pass & 1u], (unsigned)__popcll(m));
+        base = (unsigned)__builtin_amdgcn_readlane((int)base, leader);
+        if (enqueue) {
+            const unsigned idx = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+            wv.ray_o[idx] = make_float4(rq.o.x, rq.o.y, rq.o.z, rq.tmax);
+            wv.ray_d[idx] = make_float4(rq.d.x, rq.d.y, rq.d.z, prt_u2f((unsigned)id | (rq_any ? 0x80000000u : 0u)));
+        }
+    }
+    if (fa.unfinished) {
+        const unsigned long long u = __ballot(active);
+        if (u && lane == (int)__builtin_ctzll(u)) atomicAdd(fa.unfinished, (unsigned long long)__popcll(u));
+    }
+}
+
+#ifndef PT_TRAV_WAVES
+#define PT_TRAV_WAVES 8     // 64 VGPRs: the walk is a chain of dependent fetches, occupancy is what hides it
+#endif
+__global__ __launch_bounds__(256, PT_TRAV_WAVES) void wf_trav_kernel(const DevScene sc, const DevWave wv, const unsigned pass) {
+    __shared__ unsigned lds_stack[16 * 256];
+    unsigned deep_stack[PT_STACK_DEPTH - 16];
+    TravStack stk;
+    stk.lds = lds_stack + threadIdx.x; stk.stride = 256; stk.deep = deep_stack; stk.lds_levels = 16;
+    const unsigned n = wv.qcount[pass & 1u];
+    if (blockIdx.x == 0 && threadIdx.x == 0) wv.qcount[(pass + 1u) & 1u] = 0;       // next pass appends to the other counter
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const float4 a = wv.ray_o[i], b = wv.ray_d[i];
+        const unsigned ob = prt_f2u(b.w);
+        TravReq rq;
+        rq.want = true; rq.o = F3(a.x, a.y, a.z); rq.d = F3(b.x, b.y, b.z); rq.tmax = a.w;
+        const TravRes r = walk(sc, (ob >> 31) != 0, rq, stk);
+        const unsigned pix = ob & 0x7fffffffu;
+        wv.res0[pix] = make_float4(r.t, r.th.u, r.th.v, r.th.w);
+        wv.res1[pix] = r.th.slot | (r.found ? 0x80000000u : 0u);
+    }
+}
+
 __global__ void state_to_rtd(const DevState S, prt_path_state* __restrict__ out, size_t n) {
     const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n) return;
@@ -196,6 +452,26 @@ const char* launch_render(const DevScene& sc, const DevCamera& cam, const DevSta
     if (am == LD) { launch_variant<LD, true>(sc, cam, S, fa, fb, stream); return "render_kernel<LIGHT|DIFF,medium>"; }
     launch_variant<0u, true>(sc, cam, S, fa, fb, stream);
     return "render_kernel<generic,medium>";
+}
+
+template <unsigned MATS, bool MEDIUM>
+static void launch_wf_variant(const DevScene& sc, const DevCamera& cam, const DevState& S, const DevWave& wv, const FrameArgs& fa,
+                              float4* fb, unsigned pass, hipStream_t stream) {
+    const unsigned tiles_x = ((unsigned)fa.width + 15u) / 16u, tiles_y = (unsigned)((fa.rows + 15) >> 4);
+    hipLaunchKernelGGL((wf_shade_kernel<MATS, MEDIUM>), dim3(tiles_x * tiles_y), dim3(256), 0, stream, sc, cam, S, wv, fa, fb, pass);
+}
+void launch_wf_pass(const DevScene& sc, const DevCamera& cam, const DevState& S, const DevWave& wv, const FrameArgs& fa, float4* fb,
+                    unsigned pass, unsigned trav_blocks, hipStream_t stream) {
+    constexpr unsigned LD = PRT_MAT_LIGHT | PRT_MAT_DIFF;
+    const unsigned am = sc.active_mats;
+    if (!sc.has_medium) {
+        if (am == LD) launch_wf_variant<LD, false>(sc, cam, S, wv, fa, fb, pass, stream);
+        else launch_wf_variant<0u, false>(sc, cam, S, wv, fa, fb, pass, stream);
+    } else {
+        if (am == LD) launch_wf_variant<LD, true>(sc, cam, S, wv, fa, fb, pass, stream);
+        else launch_wf_variant<0u, true>(sc, cam, S, wv, fa, fb, pass, stream);
+    }
+    hipLaunchKernelGGL(wf_trav_kernel, dim3(trav_blocks), dim3(256), 0, stream, sc, wv, pass);
 }
 
 void launch_state_to_rtd(const DevState& S, prt_path_state* out, size_t n, hipStream_t stream) {

@@ -11,6 +11,9 @@ namespace prt {
 // build, include/CL/cl_kernel.h); returns the variant's name for profiles/stats
 const char* launch_render(const DevScene& sc, const DevCamera& cam, const DevState& S, const FrameArgs& fa, float4* fb,
                           hipStream_t stream);
+// one wavefront pass: shade (resume / start, suspend at deep walks) + traverse the compacted queue
+void launch_wf_pass(const DevScene& sc, const DevCamera& cam, const DevState& S, const DevWave& wv, const FrameArgs& fa, float4* fb,
+                    unsigned pass, unsigned trav_blocks, hipStream_t stream);
 void launch_state_to_rtd(const DevState& S, prt_path_state* out, size_t n, hipStream_t stream);
 void launch_rtd_to_state(const prt_path_state* in, const DevState& S, float4* fb, size_t n, hipStream_t stream);
 void launch_selftest_math(int fn, const float* a, const float* b, float* out, int n, hipStream_t stream);

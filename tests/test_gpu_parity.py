@@ -216,3 +216,37 @@ def test_dragon_standin_matches_oracle(prt, oracle):
     ostate, oimg = oracle.Restatement().render(cfg, scene.desc, cam, W, H, seeds, threads=16)
     _assert_same(oracle, ostate, oimg, r.read_state(), r.read_framebuffer(), "dragon stand-in")
     r.close()
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS))
+def test_wavefront_pipeline_matches_golden_and_megakernel(prt, oracle, variant):
+    """the alternative pipeline (shading kernel + lean traversal kernel over a compacted ray queue, pixels
+    allowed to drift in frame number) must give the same bits as the megakernel and the reference golden"""
+    g = np.load(os.path.join(GOLDEN, variant + ".npz"))
+    W, H, frames = int(g["width"]), int(g["height"]), int(g["frames"])
+    scene, cfg, cam, env, r = _setup(prt, variant, W, H)
+    r.set_pipeline("wavefront")
+    r.render_frames(prt.seed_pairs(frames))
+    gstate = np.ascontiguousarray(g["state"]).view(oracle.PATH_STATE_DTYPE).reshape(-1)
+    _assert_same(oracle, gstate, g["image"], r.read_state(), r.read_framebuffer(), variant + " wavefront vs golden")
+    # continue in the OTHER pipeline from the same state: the state is pipeline-independent
+    more = prt.seed_pairs(frames + 20)[2 * frames:]
+    r.set_pipeline("mega")
+    r.render_frames(more, first_frame=frames + 1)
+    s_mix, i_mix = r.read_state(), r.read_framebuffer()
+    r.close()
+    scene, cfg, cam, env, r2 = _setup(prt, variant, W, H)
+    r2.render_frames(prt.seed_pairs(frames + 20))
+    _assert_same(oracle, r2.read_state().view(oracle.PATH_STATE_DTYPE), r2.read_framebuffer(), s_mix, i_mix, variant + " wavefront+mega vs mega")
+    r2.close()
+
+
+def test_wavefront_spp_mode(prt, oracle):
+    g = np.load(os.path.join(GOLDEN, "cornell_diffuse_spp.npz"))
+    W, H, maxf, spp = int(g["width"]), int(g["height"]), int(g["frames"]), int(g["spp"])
+    scene, cfg, cam, env, r = _setup(prt, "cornell_diffuse", W, H)
+    r.set_pipeline(1)
+    r.render_spp(spp, prt.seed_pairs(maxf))
+    gstate = np.ascontiguousarray(g["state"]).view(oracle.PATH_STATE_DTYPE).reshape(-1)
+    _assert_same(oracle, gstate, g["image"], r.read_state(), r.read_framebuffer(), "wavefront spp golden")
+    r.close()
