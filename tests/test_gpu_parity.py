@@ -250,3 +250,49 @@ def test_wavefront_spp_mode(prt, oracle):
     gstate = np.ascontiguousarray(g["state"]).view(oracle.PATH_STATE_DTYPE).reshape(-1)
     _assert_same(oracle, gstate, g["image"], r.read_state(), r.read_framebuffer(), "wavefront spp golden")
     r.close()
+
+
+def test_full_size_frame_against_oracle_strips_and_properties(prt, oracle):
+    """BASELINE config 2 at its real size (1920x1080): the oracle renders three 4-row strips of the frame
+    (global pixel coordinates) and must match the GPU's full-frame pixels bit for bit; plus the
+    size-independent properties: interleaved row blocks == full frame, frame batches compose, counters add up."""
+    W, H, frames = 1920, 1080, 40
+    scene, cfg, cam, env, r = _setup(prt, "cornell_diffuse", W, H)
+    seeds = prt.seed_pairs(frames)
+    r.render_frames(seeds[:2 * 17])
+    r.render_frames(seeds[2 * 17:], first_frame=18)                       # two batches
+    img = r.read_framebuffer()
+    state = r.read_state().reshape(H, W)
+    st = r.counts()
+    assert st.segments == frames * W * H                                   # every pixel advances one segment per frame (Q19)
+    assert st.samples == int(state["samples"].sum()) and int(state["acc"][..., 3].sum()) == st.segments
+    r.close()
+    rs = oracle.Restatement()
+    for row0 in (0, 538, 1076):
+        ostate, oimg = rs.render(cfg, scene.desc, cam, W, H, seeds, row0=row0, rows=4, threads=16)
+        _assert_same(oracle, ostate, oimg, state[row0:row0 + 4].reshape(-1), img[row0:row0 + 4], "full-size strip at row %d" % row0)
+    # the multi-GPU partition at full size: 8 parts, check two of them
+    for part in (0, 5):
+        rows = np.array([y for y in range(H) if (y // 16) % 8 == part])
+        rt = prt.Renderer(cfg, device=0)
+        rt.upload_scene(scene)
+        rt.set_camera(cam)
+        rt.set_row_blocks(W, H, 16, 8, part)
+        rt.render_frames(seeds)
+        _assert_same(oracle, state[rows].reshape(-1).view(oracle.PATH_STATE_DTYPE), img[rows], rt.read_state(), rt.read_framebuffer(),
+                     "full-size row blocks, part %d of 8" % part)
+        rt.close()
+
+
+def test_full_size_spp_render_is_complete(prt, oracle):
+    """1920x1080 at 8 spp to completion: every pixel froze at exactly 8 paths, alpha = segments / samples"""
+    W, H, spp = 1920, 1080, 8
+    scene, cfg, cam, env, r = _setup(prt, "cornell_diffuse", W, H)
+    r.render_spp(spp, prt.seed_pairs(spp * cfg.max_bounces + 64))
+    st = r.counts(spp)
+    assert st.finished_pixels == W * H and st.samples == spp * W * H
+    img = r.read_framebuffer()
+    state = r.read_state()
+    assert np.isfinite(img).all() and (img[..., :3] >= 0).all()
+    assert np.array_equal(img[..., 3].reshape(-1), state["acc"][:, 3] / np.float32(spp))
+    r.close()
