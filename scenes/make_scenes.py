@@ -63,7 +63,18 @@ SCENES = {
                              medium={"density": 0.07, "sigmaA": 0.0, "sigmaS": 1.0},
                              st=settings(12, 4, 16, 32, 1024)),
     "cornell_dragon": cornell({"color": WHITE, "type": 1}, obj="dragon_standin.prtmesh"),
+    # coverage scenes (not BASELINE configs): every material / distribution / light type of SURVEY s8a
+    "cornell_mixed": cornell({"color": [0.9, 0.8, 0.6], "type": 10, "dist": 1, "roughness": 0.25},          # ROUGH_COND, Phong
+                             extra_spheres=[{"pos": [-1.1, 0.45, 0.6], "radius": 0.45, "material": {"color": [0.95, 0.95, 0.95], "type": 2}},               # COND mirror
+                                            {"pos": [1.1, 0.5, 0.9], "radius": 0.5, "material": {"color": [0.6, 0.9, 0.7], "type": 3, "absorptive": 1}},    # DIEL, ABS_REFR
+                                            {"pos": [0.2, 0.35, 1.4], "radius": 0.35,
+                                             "material": {"color": [0.9, 0.7, 0.9], "type": 11, "dist": 0, "roughness": 0.15, "absorptive": 2}}]),          # ROUGH_DIEL Beckmann, ABS_REFR2
+    "cornell_quadlight": {"settings": settings(16, 6, 16, 16, 16),
+                          "scene": {"obj": {"path": "teapot.obj", "material": {"color": WHITE, "type": 4, "dist": 2, "roughness": 0.2}},   # COAT over GGX
+                                    "spheres": [{"pos": [1.0, 0.4, -0.8], "radius": 0.4, "material": {"color": [0.7, 0.7, 0.9], "type": 1}}],
+                                    "quads": [quad([0.0, 3.95, 0.0], [-1.2, 0.0, 0.0], [0.0, 0.0, 1.2], [12.0, 12.0, 12.0])] + box_quads()}},
 }
+SCENES["cornell_quadlight"]["scene"]["quads"][0]["material"]["type"] = 0        # the quad is the (only) light
 
 if __name__ == "__main__":
     for name, doc in SCENES.items():

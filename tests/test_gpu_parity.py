@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, VARIANTS
+from conftest import ALPHA_VARIANTS, GOLDEN, VARIANTS
 
 pytestmark = pytest.mark.gpu
 
@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 def _setup(prt, variant, W, H, rows=None, row0=0):
     scene_json, phase, use_env = VARIANTS[variant]
     scene = prt.HostScene(scene_json)
-    cfg = scene.config()
+    cfg = scene.config(alpha_testing=variant in ALPHA_VARIANTS)
     cfg.phase_function = phase
     cam = prt.default_camera(W, H)
     env = prt.make_sky(64, 32) if use_env else None

@@ -6,13 +6,13 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, VARIANTS
+from conftest import ALPHA_VARIANTS, GOLDEN, VARIANTS
 
 
 def setup(prt, variant, W, H):
     scene_json, phase, use_env = VARIANTS[variant]
     scene = prt.HostScene(scene_json)
-    cfg = scene.config()
+    cfg = scene.config(alpha_testing=variant in ALPHA_VARIANTS)
     cfg.phase_function = phase
     return scene, cfg, prt.default_camera(W, H), (prt.make_sky(64, 32) if use_env else None)
 
