@@ -296,3 +296,17 @@ def test_full_size_spp_render_is_complete(prt, oracle):
     assert np.isfinite(img).all() and (img[..., :3] >= 0).all()
     assert np.array_equal(img[..., 3].reshape(-1), state["acc"][:, 3] / np.float32(spp))
     r.close()
+
+
+def test_axis_parallel_rays_nan_slabs(prt, oracle):
+    """centre column of a pinhole camera at odd width: dir.x == 0, origin.x == 0 -> inf / NaN slabs; the device's
+    v_min_f32 / v_max_f32 must treat the NaN like the oracle's fmin / fmax"""
+    W, H, frames = 33, 21, 80
+    scene, cfg, cam, env, r = _setup(prt, "cornell_coat", W, H)
+    cam = prt.orbit_camera(W, H, d_aperture=-1.0)
+    r.set_camera(cam)
+    seeds = prt.seed_pairs(frames)
+    r.render_frames(seeds)
+    ostate, oimg = oracle.Restatement().render(cfg, scene.desc, cam, W, H, seeds, threads=8)
+    _assert_same(oracle, ostate, oimg, r.read_state(), r.read_framebuffer(), "axis-parallel rays")
+    r.close()

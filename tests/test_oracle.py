@@ -106,3 +106,21 @@ def test_dragon_standin_oracle_equals_reference_build(prt, oracle):
     state, img = rs.render(cfg, scene.desc, cam, W, H, seeds, threads=8)
     assert oracle.state_fields_equal(rstate, state) == [] and oracle.images_equal(rimg, img)
     assert rs.last_diag[1] > 8          # the any-hit stack really goes deeper than the reference's 8 entries
+
+
+def test_axis_parallel_rays_nan_slabs(prt, oracle):
+    """pinhole camera + odd width: the centre column has dir.x == 0 and origin.x == 0 exactly, so the slab test
+    (bvh.cl:4-9) produces inf and NaN (0 * inf) in every node -- fmin/fmax must ignore the NaN operand exactly as
+    the reference build does"""
+    if not oracle.ref_available("cornell_coat"):
+        pytest.skip("oracle/_ref not built")
+    W, H, frames = 33, 21, 60
+    scene, cfg, _, env = setup(prt, "cornell_coat", W, H)
+    cam = prt.orbit_camera(W, H, d_aperture=-1.0)                          # apertureRadius clamps to 0: pinhole
+    assert cam.apertureRadius == 0.0 and cam.view[0] == 0.0 and cam.position[0] == 0.0
+    seeds = prt.seed_pairs(frames)
+    rstate, rimg = oracle.RefOracle("cornell_coat").render(scene.desc, bytes(cam), W, H, seeds, threads=4)
+    state, img = oracle.Restatement().render(cfg, scene.desc, cam, W, H, seeds, threads=4)
+    assert oracle.state_fields_equal(rstate, state) == [] and oracle.images_equal(rimg, img)
+    # premise (by construction, camera.cl:26-52): view.x = up.x = position.x = 0 -> hAxis = (+-1,0,0), vAxis.x = 0,
+    # and at x = (W-1)/2 the factor 2*sx-1 is exactly 0, so origin.x = dir.x = 0 for the whole centre column
