@@ -217,18 +217,39 @@ extern "C" int prt_upload_scene(prt_ctx* c, const prt_scene_desc* s) {
         } else {
             sc.root_is_leaf = 0;
             std::vector<uint32_t> pair_of(N, 0xFFFFFFFFu);
-            std::vector<uint32_t> order;           // inner nodes in breadth-first order: top levels first (they go to LDS)
-            order.push_back(0);
-            pair_of[0] = 0;
-            for (size_t head = 0; head < order.size(); ++head) {
-                const uint32_t n = order[head];
-                const uint32_t fc = nodes[n].first_child_or_primitive;
-                if ((uint64_t)fc + 1 >= N) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: BVH child index out of range");
-                for (uint32_t ch = fc; ch <= fc + 1; ++ch) {
-                    if (nodes[ch].is_leaf) continue;
-                    if (pair_of[ch] != 0xFFFFFFFFu || order.size() >= N) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: BVH is not a tree");
-                    pair_of[ch] = (uint32_t)order.size();
-                    order.push_back(ch);
+            // Order of the NodePair records in memory.  Breadth-first keeps the top of the tree (which every ray
+            // walks) contiguous; depth-first (pre-order, left child right behind its parent) gives deep walks through
+            // big trees better line / page locality.  PRT_PAIR_ORDER=bfs|dfs overrides the choice.
+            std::vector<uint32_t> order;
+            const char* e_order = std::getenv("PRT_PAIR_ORDER");
+            const bool dfs = e_order ? (std::strcmp(e_order, "dfs") == 0) : (N > 65536u);
+            order.reserve(N / 2 + 1);
+            if (!dfs) {
+                order.push_back(0);
+                pair_of[0] = 0;
+                for (size_t head = 0; head < order.size(); ++head) {
+                    const uint32_t n = order[head];
+                    const uint32_t fc = nodes[n].first_child_or_primitive;
+                    if ((uint64_t)fc + 1 >= N) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: BVH child index out of range");
+                    for (uint32_t ch = fc; ch <= fc + 1; ++ch) {
+                        if (nodes[ch].is_leaf) continue;
+                        if (pair_of[ch] != 0xFFFFFFFFu || order.size() >= N) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: BVH is not a tree");
+                        pair_of[ch] = (uint32_t)order.size();
+                        order.push_back(ch);
+                    }
+                }
+            } else {
+                std::vector<uint32_t> st{0};
+                while (!st.empty()) {
+                    const uint32_t n = st.back();
+                    st.pop_back();
+                    if (n >= N || pair_of[n] != 0xFFFFFFFFu || order.size() >= N) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: BVH is not a tree");
+                    pair_of[n] = (uint32_t)order.size();
+                    order.push_back(n);
+                    const uint32_t fc = nodes[n].first_child_or_primitive;
+                    if ((uint64_t)fc + 1 >= N) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: BVH child index out of range");
+                    if (!nodes[fc + 1].is_leaf) st.push_back(fc + 1);
+                    if (!nodes[fc].is_leaf) st.push_back(fc);
                 }
             }
             pairs.resize(order.size());

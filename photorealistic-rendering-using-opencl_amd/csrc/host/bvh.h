@@ -20,7 +20,9 @@ using cl_BVHnode = prt_bvh_node;
 
 class BVH {
 public:
-    explicit BVH(const std::shared_ptr<IO::ModelLoader>& ml, unsigned max_leaf_size = 16, float traversal_cost = 1.0f);
+    // traversal_cost <= 0 picks the measured optimum: 1 for small meshes (teapot: fatter leaves are monotonically
+    // slower on MI355X), 2.5 from 64 k triangles up (871 k-triangle mesh: +9 %, the tree is two levels shallower)
+    explicit BVH(const std::shared_ptr<IO::ModelLoader>& ml, unsigned max_leaf_size = 16, float traversal_cost = 0.0f);
     std::unique_ptr<std::vector<uint64_t>> GetPrimitiveIndices() const;
     std::unique_ptr<std::vector<cl_BVHnode>> PrepareData() const;
     size_t node_count() const { return nodes_.size(); }

@@ -36,7 +36,7 @@ static prth_scene* finish_load(std::unique_ptr<prth_scene> h, const char* models
         // PRT_BVH_LEAF / PRT_BVH_COST override them for experiments
         const char* e_leaf = std::getenv("PRT_BVH_LEAF");
         const char* e_cost = std::getenv("PRT_BVH_COST");
-        prt::BVH bvh(h->ml, e_leaf ? (unsigned)std::atoi(e_leaf) : 16u, e_cost ? (float)std::atof(e_cost) : 1.0f);
+        prt::BVH bvh(h->ml, e_leaf ? (unsigned)std::atoi(e_leaf) : 16u, e_cost ? (float)std::atof(e_cost) : 0.0f);
         h->nodes = *bvh.PrepareData();
         h->indices = *bvh.GetPrimitiveIndices();
         h->bvh_depth = bvh.max_depth();
