@@ -66,10 +66,18 @@ def main():
         a.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libprt has no CPU fallback")
+    # rehearsal knobs for a 1-GPU box: PRT_BENCH_BACKEND=gloo + PRT_BENCH_ONE_DEVICE=1 run N ranks on cuda:0
+    one_device = os.environ.get("PRT_BENCH_ONE_DEVICE") == "1"
+    backend = os.environ.get("PRT_BENCH_BACKEND", "nccl")
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     prt = importlib.import_module(PKG_NAME)
     par = importlib.import_module(PKG_NAME + ".parallel")
