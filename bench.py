@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--scene", default="cornell_diffuse.json")
     ap.add_argument("--env", default="", choices=["", "sky"], help="sky = the procedural 1024x512 HDR stand-in (configs 3, 4)")
-    ap.add_argument("--phase", default="isotropic", choices=["isotropic", "hg"], help="phase function of the global medium (config 4)")
+    ap.add_argument("--phase", default="isotropic", choices=["isotropic", "hg", "rayleigh"], help="phase function of the global medium (config 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -90,7 +90,7 @@ def main():
         prt.ensure_dragon_standin()
     scene = prt.HostScene(a.scene)
     cfg = scene.config()
-    cfg.phase_function = 1 if a.phase == "hg" else 0
+    cfg.phase_function = {"isotropic": 0, "hg": 1, "rayleigh": 2}[a.phase]
     cam = prt.default_camera(W, H)
     max_frames = max(64, spp * max(cfg.max_bounces, 8) + 64)      # a path has at most max_bounces (+1) segments
     seeds = prt.seed_pairs(max_frames)
@@ -216,7 +216,7 @@ def cpu_baseline(prt, a):
     cores = max(1, min(cores, 64))
     scene = prt.HostScene(a.scene)
     cfg = scene.config()
-    cfg.phase_function = 1 if a.phase == "hg" else 0
+    cfg.phase_function = {"isotropic": 0, "hg": 1, "rayleigh": 2}[a.phase]
     cam = prt.default_camera(W, H)
     seeds = prt.seed_pairs(spp * max(cfg.max_bounces, 8) + 64)
     env = prt.make_sky(1024, 512) if a.env == "sky" else None

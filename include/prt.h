@@ -40,8 +40,8 @@ typedef enum prt_status {
 
 /* phase function of the global medium.  The reference wires Isotropic at source level
  * (kernels/media.cl:61); HG (g fixed 0.6, kernels/phasefunctions/HenyeyGreenstein.cl:4) and
- * Rayleigh exist as files.  Here it is a run-time choice. */
-typedef enum prt_phase { PRT_PHASE_ISOTROPIC = 0, PRT_PHASE_HG = 1 } prt_phase;
+ * Rayleigh (kernels/phasefunctions/Rayleigh.cl) exist as files.  Here it is a run-time choice. */
+typedef enum prt_phase { PRT_PHASE_ISOTROPIC = 0, PRT_PHASE_HG = 1, PRT_PHASE_RAYLEIGH = 2 } prt_phase;
 
 /*
  * The scene-specialisation parameters of the reference's kernel builder
@@ -169,7 +169,7 @@ int prt_query_counts(prt_ctx* ctx, uint32_t spp, prt_stats* stats);
 
 /* Diagnostics: evaluates one function of include/prt_detmath.h ON THE DEVICE for n inputs
  * (fn: 0 sin, 1 cos, 2 tan, 3 exp, 4 log, 5 acos, 6 atan2(a,b), 7 pow(a,b), 8 sqrt, 9 a/b,
- * 10 fma(a,b,a), 11 fmin(a,b), 12 fmax(a,b), 13 round, 14 floor, 15 1/a).  Host arrays in and out.
+ * 10 fma(a,b,a), 11 fmin(a,b), 12 fmax(a,b), 13 round, 14 floor, 15 1/a, 16 cbrt).  Host arrays in and out.
  * The numerics contract says the result must equal the host evaluation bit for bit. */
 int prt_selftest_math(prt_ctx* ctx, int fn, const float* a, const float* b, float* out, int n);
 

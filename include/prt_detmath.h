@@ -17,7 +17,7 @@
  *         reference's own kernel text run on the host).
  *
  * Accuracy (tests/test_detmath.py, against float64 libm): sin/cos <= 2 ulp on |x| <= 1e4, tan <= 4 ulp,
- * exp/log <= 2 ulp, acos/atan2 <= 3 ulp, pow(x,2) exact, general pow <= ~(4+4|y ln x|) ulp.
+ * exp/log <= 2 ulp, acos/atan2 <= 3 ulp, cbrt <= 2 ulp, pow(x,2) exact, general pow <= ~(4+4|y ln x|) ulp.
  * All inside the OpenCL 1.2 full-profile bounds except general pow with huge exponents.
  */
 #ifndef PRT_DETMATH_H
@@ -201,6 +201,26 @@ PRT_HD float prt_pow(float x, float y) {
     if (x == 0.0f) return (y > 0.0f) ? 0.0f : prt_u2f(0x7f800000u);
     if (x < 0.0f) return prt_u2f(0x7fc00000u);      /* negative bases are never used by the path */
     return prt_exp(y * prt_log(x));
+}
+
+/* ---- cbrt (kernels/phasefunctions/Rayleigh.cl:24) ------------------------------------------------------ */
+PRT_HD float prt_cbrt(float x) {
+    if (x != x || x == 0.0f) return x;
+    unsigned ux = prt_f2u(x);
+    const unsigned sign = ux & 0x80000000u;
+    ux &= 0x7fffffffu;
+    if (ux == 0x7f800000u) return x;
+    float ax = prt_u2f(ux);
+    int e = 0;
+    if (ux < 0x00800000u) { ax *= 16777216.0f; ux = prt_f2u(ax); e = -8; }     /* subnormal: scale by 2^24 = (2^8)^3 */
+    /* initial guess: exponent / 3 by integer arithmetic on the bit pattern, then 4 Newton steps y -= (y^3 - a) / (3 y^2) */
+    float y = prt_u2f(ux / 3u + 0x2a5137a0u);
+    for (int i = 0; i < 4; ++i) {
+        const float y2 = y * y;
+        y = y - prt_fma(y2, y, -ax) / (3.0f * y2);
+    }
+    if (e) y *= 0.00390625f;                                                    /* 2^-8 */
+    return prt_u2f(prt_f2u(y) | sign);
 }
 
 /* ---- inverse trigonometry --------------------------------------------------------------- */

@@ -22,6 +22,7 @@ void detmath_probe(int fn, const float* a, const float* b, float* out, int n) {
             case 12: r = prt_fmax(x, y); break;
             case 13: r = prt_round(x); break;
             case 14: r = prt_floor(x); break;
+            case 16: r = prt_cbrt(x); break;
             default: r = prt_recip(x); break;
         }
         out[i] = r;

@@ -855,16 +855,32 @@ static float hg(float g, float cosTheta) {
     float term = 1.0f + g * g - 2.0f * g * cosTheta;
     return INV_FOUR_PI * (1.0f - g * g) / (term * prt_sqrt(term));
 }
+static float rayleigh(float cosTheta) { return (3.0f / (16.0f * PI)) * (1.0f + cosTheta * cosTheta); }   /* Rayleigh.cl:4-6 */
 static v3 phase_eval(const Scene* sc, v3 wi, v3 wo) {
+    if (sc->cfg->phase_function == PRT_PHASE_RAYLEIGH) return vsplat(rayleigh(vdot(wi, wo)));
     if (sc->cfg->phase_function == PRT_PHASE_HG) return vsplat(hg(sc->cfg->phase_g, vdot(wi, wo)));
     return vsplat(INV_FOUR_PI);
 }
 static float phase_pdf(const Scene* sc, v3 wi, v3 wo) {
+    if (sc->cfg->phase_function == PRT_PHASE_RAYLEIGH) return rayleigh(vdot(wi, wo));
     if (sc->cfg->phase_function == PRT_PHASE_HG) return hg(sc->cfg->phase_g, vdot(wi, wo));
     return INV_FOUR_PI;
 }
 static int phase_sample(const Scene* sc, v3 wi, PhaseSample* ps, Rng* rng) {
     float xi_x = next1D(rng), xi_y = next1D(rng);
+    if (sc->cfg->phase_function == PRT_PHASE_RAYLEIGH) {                /* Rayleigh.cl:16-39 */
+        float phi = xi_x * TWO_PI;
+        float z = xi_y * 4.0f - 2.0f;
+        float invZ = prt_sqrt(z * z + 1.0f);
+        float u = prt_cbrt(z + invZ);
+        float cosTheta = u - 1.0f / u;
+        float sinTheta = prt_sqrt(prt_fmax(1.0f - cosTheta * cosTheta, 0.0f));
+        TangentFrame tf = createTangentFrame(wi);
+        ps->w = toGlobal(&tf, V(prt_cos(phi) * sinTheta, prt_sin(phi) * sinTheta, cosTheta));
+        ps->weight = vsplat(1.0f);
+        ps->pdf = rayleigh(cosTheta);
+        return 1;
+    }
     if (sc->cfg->phase_function == PRT_PHASE_HG) {
         const float g = sc->cfg->phase_g;
         if (g == 0.0f) {

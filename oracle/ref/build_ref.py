@@ -72,7 +72,7 @@ def set_phase(tmp, phase):
     line of kernels/media.cl:61.  Same effect without touching text: point the
     farm's Isotropic.cl link at the requested file."""
     link = os.path.join(tmp, "kernels", "phasefunctions", "Isotropic.cl")
-    target = {"": "Isotropic.cl", "isotropic": "Isotropic.cl", "hg": "HenyeyGreenstein.cl"}[phase]
+    target = {"": "Isotropic.cl", "isotropic": "Isotropic.cl", "hg": "HenyeyGreenstein.cl", "rayleigh": "Rayleigh.cl"}[phase]
     os.remove(link)
     os.symlink(os.path.join(REF, "kernels", "phasefunctions", target), link)
 
@@ -126,7 +126,7 @@ def main():
     ap.add_argument("--height", type=int, default=64)
     ap.add_argument("--alpha", action="store_true")
     ap.add_argument("--shadow-stack", type=int, default=64)
-    ap.add_argument("--phase", default="", choices=["", "isotropic", "hg"], help="phase function of the global medium")
+    ap.add_argument("--phase", default="", choices=["", "isotropic", "hg", "rayleigh"], help="phase function of the global medium")
     ap.add_argument("--blob-dir", default=os.path.join(ROOT, "tests", "golden"))
     a = ap.parse_args()
     if not os.path.isdir(REF):

@@ -86,6 +86,7 @@ float native_cos(float x) { return prt_cos(x); }
 float native_exp(float x) { return prt_exp(x); }
 float native_log(float x) { return prt_log(x); }
 float native_sqrt(float x) { return prt_sqrt(x); }
+float cbrt(float x) { return prt_cbrt(x); }
 float native_recip(float x) { return prt_recip(x); }
 float shim_fract1(float x, float* ip) __asm__("_Z5fractfPU9CLprivatef");
 float shim_fract1(float x, float* ip) { *ip = prt_floor(x); return prt_fract(x); }

@@ -869,7 +869,9 @@ PT_DEV float hg(float g, float cosTheta) {
     float term = 1.0f + g * g - 2.0f * g * cosTheta;
     return PT_INV_FOUR_PI * (1.0f - g * g) / (term * prt_sqrt(term));
 }
+PT_DEV float rayleigh(float cosTheta) { return (3.0f / (16.0f * PT_PI)) * (1.0f + cosTheta * cosTheta); }   // Rayleigh.cl:4-6
 PT_DEV float phase_value(const DevScene& sc, f3 wi, f3 wo) {    // phase_eval (splat) == phase_pdf
+    if (sc.phase_function == 2) return rayleigh(dot(wi, wo));
     if (sc.phase_function == 1) return hg(sc.phase_g, dot(wi, wo));
     return PT_INV_FOUR_PI;
 }
@@ -877,7 +879,17 @@ struct PhaseSample { f3 w, weight; float pdf; };
 PT_DEV void phase_sample(const DevScene& sc, f3 wi, PhaseSample& ps, Rng& rng) {
     float xi_x = next1D(rng), xi_y = next1D(rng);
     ps.weight = splat(1.0f);
-    if (sc.phase_function == 1 && sc.phase_g != 0.0f) {
+    if (sc.phase_function == 2) {                                   // Rayleigh.cl:16-39
+        float phi = xi_x * PT_TWO_PI;
+        float z = xi_y * 4.0f - 2.0f;
+        float invZ = prt_sqrt(z * z + 1.0f);
+        float u = prt_cbrt(z + invZ);
+        float cosTheta = u - 1.0f / u;
+        float sinTheta = prt_sqrt(prt_fmax(1.0f - cosTheta * cosTheta, 0.0f));
+        Frame tf = make_frame(wi);
+        ps.w = to_global(tf, F3(prt_cos(phi) * sinTheta, prt_sin(phi) * sinTheta, cosTheta));
+        ps.pdf = rayleigh(cosTheta);
+    } else if (sc.phase_function == 1 && sc.phase_g != 0.0f) {
         const float g = sc.phase_g;
         float phi = xi_x * PT_TWO_PI;
         float q = (1.0f - g * g) / (1.0f + g * (xi_y * 2.0f - 1.0f));

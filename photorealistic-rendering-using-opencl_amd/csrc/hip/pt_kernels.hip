@@ -424,6 +424,7 @@ __global__ void selftest_math_kernel(int fn, const float* __restrict__ a, const 
         case 12: r = prt_fmax(x, y); break;
         case 13: r = prt_round(x); break;
         case 14: r = prt_floor(x); break;
+        case 16: r = prt_cbrt(x); break;
         default: r = prt_recip(x); break;
     }
     out[i] = r;

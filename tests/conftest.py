@@ -45,6 +45,7 @@ VARIANTS = {
     "cornell_roughdiel": ("cornell_roughdiel.json", 0, True),
     "cornell_media": ("cornell_media.json", 0, True),
     "cornell_media_hg": ("cornell_media.json", 1, True),
+    "cornell_media_rayleigh": ("cornell_media.json", 2, True),
     "cornell_mixed": ("cornell_mixed.json", 0, True),           # Phong rough conductor, mirror, absorbing (rough) dielectrics
     "cornell_quadlight": ("cornell_quadlight.json", 0, False),  # quad area light, coat over GGX, -alpha
 }

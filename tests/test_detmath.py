@@ -10,7 +10,7 @@ import pytest
 from conftest import ROOT
 
 FN = {"sin": 0, "cos": 1, "tan": 2, "exp": 3, "log": 4, "acos": 5, "atan2": 6, "pow": 7, "sqrt": 8, "div": 9,
-      "fma": 10, "fmin": 11, "fmax": 12, "round": 13, "floor": 14, "recip": 15}
+      "fma": 10, "fmin": 11, "fmax": 12, "round": 13, "floor": 14, "recip": 15, "cbrt": 16}
 
 
 @pytest.fixture(scope="module")
@@ -50,6 +50,8 @@ def test_accuracy_against_libm(probe):
     assert ulp_err(probe("acos", a), np.arccos(a.astype(np.float64))).max() < 3.0
     y, xx = rng.uniform(-10, 10, 400000).astype(np.float32), rng.uniform(-10, 10, 400000).astype(np.float32)
     assert ulp_err(probe("atan2", y, xx), np.arctan2(y.astype(np.float64), xx.astype(np.float64))).max() < 3.0
+    cb = np.concatenate([rng.uniform(-30, 30, 200000), np.exp(rng.uniform(-100, 85, 200000))]).astype(np.float32)
+    assert ulp_err(probe("cbrt", cb), np.cbrt(cb.astype(np.float64))).max() < 2.0
     p = rng.uniform(0.01, 3, 100000).astype(np.float32)
     assert np.array_equal(probe("pow", p, np.full_like(p, 2.0)), p * p)                # exact
     q = rng.uniform(-4, 4, 100000).astype(np.float32)
