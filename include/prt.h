@@ -151,8 +151,14 @@ int prt_set_pipeline(prt_ctx* ctx, int pipeline);
 
 int prt_synchronize(prt_ctx* ctx);
 
-/* output texture: linear float4 acc/samples per pixel, row 0 = top (kernels/main.cl:159). */
+/* output texture: linear float4 acc/samples per pixel (kernels/main.cl:159).  Row 0 is the BOTTOM of the
+ * picture, as in the reference's GL texture (the camera maps coord.y = 0 to the lowest scan line,
+ * kernels/camera.cl:29-35; its PNG writer flips on write, include/GL/cl_gl_interop.h:139). */
 int prt_read_framebuffer(prt_ctx* ctx, float* rgba);
+/* display side ("next" row N3): the reference's fragment shader (shaders/tonemapper.glsl:47-64: vignette,
+ * filmic Reinhard with white point 1.2, smoothstep, gamma 2.2) applied on the device; 8-bit RGBA out, rows in
+ * framebuffer order (what glReadPixels returns, include/GL/cl_gl_interop.h:147-150). */
+int prt_tonemap_rgba8(prt_ctx* ctx, uint8_t* rgba);
 /* same, device to device, into caller-owned device memory (e.g. a torch tensor) on the context's stream */
 int prt_copy_framebuffer_to_device(prt_ctx* ctx, void* device_rgba);
 

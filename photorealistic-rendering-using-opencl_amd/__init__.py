@@ -196,6 +196,12 @@ class Renderer:
         self._chk(self.lib.prt_read_framebuffer(self.ctx, out.ctypes.data_as(C.c_void_p)), "prt_read_framebuffer")
         return out
 
+    def tonemap_rgba8(self):
+        """the reference's display transform (shaders/tonemapper.glsl) of the framebuffer, rows bottom-up"""
+        out = np.zeros((self.rows, self.width, 4), dtype=np.uint8)
+        self._chk(self.lib.prt_tonemap_rgba8(self.ctx, out.ctypes.data_as(C.c_void_p)), "prt_tonemap_rgba8")
+        return out
+
     def copy_framebuffer_to_device(self, device_ptr):
         self._chk(self.lib.prt_copy_framebuffer_to_device(self.ctx, C.c_void_p(device_ptr)), "prt_copy_framebuffer_to_device")
 

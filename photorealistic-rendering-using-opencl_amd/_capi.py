@@ -84,6 +84,7 @@ PRT_API = [
     ("prt_set_pipeline", C.c_int, [C.c_void_p, C.c_int]),
     ("prt_synchronize", C.c_int, [C.c_void_p]),
     ("prt_read_framebuffer", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("prt_tonemap_rgba8", C.c_int, [C.c_void_p, C.c_void_p]),
     ("prt_copy_framebuffer_to_device", C.c_int, [C.c_void_p, C.c_void_p]),
     ("prt_read_state", C.c_int, [C.c_void_p, C.c_void_p]),
     ("prt_write_state", C.c_int, [C.c_void_p, C.c_void_p]),

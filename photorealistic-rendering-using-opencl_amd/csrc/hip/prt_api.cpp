@@ -53,6 +53,7 @@ struct prt_ctx {
         (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_); return PRT_ERR_HIP; } } while (0)
 
 static int fail(prt_ctx* ctx, int code, const std::string& msg) { ctx->err = msg; return code; }
+static FrameArgs frame_args(prt_ctx* c, uint32_t first_frame, uint32_t n, const int32_t* d_seeds, uint32_t spp, bool count);
 
 static void free_dev(void*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
 
@@ -573,6 +574,20 @@ extern "C" int prt_read_framebuffer(prt_ctx* c, float* rgba) {
     int rc = prt_synchronize(c);
     if (rc) return rc;
     HIPCHK(c, hipMemcpy(rgba, c->fb, c->npix * 16, hipMemcpyDeviceToHost));
+    return PRT_OK;
+}
+
+extern "C" int prt_tonemap_rgba8(prt_ctx* c, uint8_t* rgba) {
+    CTX_CHECK(c);
+    if (!rgba || !c->have_size) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_tonemap_rgba8: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    unsigned char* d = nullptr;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d), c->npix * 4));
+    launch_tonemap(c->fb, d, frame_args(c, 1, 0, nullptr, 0, false), c->stream);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(rgba, d, c->npix * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    HIPCHK(c, e);
     return PRT_OK;
 }
 

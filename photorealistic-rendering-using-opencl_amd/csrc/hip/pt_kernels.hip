@@ -402,6 +402,44 @@ __global__ void count_kernel(const DevState S, size_t n, unsigned spp, unsigned 
     if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], s); atomicAdd(&out[1], g); atomicAdd(&out[2], z); }
 }
 
+// shaders/tonemapper.glsl:12-23,47-64 -- display transform of the linear framebuffer (not part of the radiance
+// loop; float accuracy of an 8-bit output is uncritical, the stated math library is used anyway)
+PT_DEV float filmic_reinhard_curve(float x) {
+    const float T2 = 7.5f;
+    float q = (T2 * T2 + 1.0f) * x * x;
+    return q / (q + x + T2 * T2);
+}
+PT_DEV float smoothstep_f(float e0, float e1, float x) {
+    float t = prt_fmin(prt_fmax((x - e0) / (e1 - e0), 0.0f), 1.0f);
+    return t * t * (3.0f - 2.0f * t);
+}
+__global__ void tonemap_kernel(const float4* __restrict__ fb, uchar4* __restrict__ out, const FrameArgs fa) {
+    const size_t npix = (size_t)fa.width * (size_t)fa.rows;
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= npix) return;
+    const int lx = (int)(id % (size_t)fa.width), ly = (int)(id / (size_t)fa.width);
+    const int gy = fa.row0 + (ly / fa.block_rows * fa.n_parts + fa.part) * fa.block_rows + ly % fa.block_rows;
+    // gl_FragCoord = pixel centre; p = 1 - 2 * fragCoord / resolution
+    const float px = 1.0f - 2.0f * ((float)lx + 0.5f) / (float)fa.width;
+    const float py = 1.0f - 2.0f * ((float)gy + 0.5f) / (float)fa.full_height;
+    float vignette = 1.25f / (1.1f + 1.1f * (px * px + py * py));
+    vignette *= vignette;
+    vignette = 1.0f * (1.0f - 0.25f) + smoothstep_f(0.1f, 1.1f, vignette) * 0.25f;             // mix(1, smoothstep(..), 0.25)
+    const float4 c = fb[id];
+    const float w = filmic_reinhard_curve(1.2f);
+    float rgb[3] = {c.x, c.y, c.z};
+    unsigned char o[3];
+    for (int k = 0; k < 3; ++k) {
+        float v = rgb[k] * vignette;
+        v = filmic_reinhard_curve(1.0f * v) / w;
+        v = smoothstep_f(-0.025f, 1.0f, v);
+        v = prt_pow(v, 1.0f / 2.2f);
+        v = prt_fmin(prt_fmax(v, 0.0f), 1.0f);                    // NaN -> 0 (prt_fmax ignores a NaN operand)
+        o[k] = (unsigned char)prt_rint(v * 255.0f);
+    }
+    out[id] = make_uchar4(o[0], o[1], o[2], 255);
+}
+
 // the same switch is evaluated on the host by oracle/detmath_probe.c
 __global__ void selftest_math_kernel(int fn, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int n) {
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -483,6 +521,10 @@ void launch_rtd_to_state(const prt_path_state* in, const DevState& S, float4* fb
 }
 void launch_selftest_math(int fn, const float* a, const float* b, float* out, int n, hipStream_t stream) {
     hipLaunchKernelGGL(selftest_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, fn, a, b, out, n);
+}
+void launch_tonemap(const float4* fb, unsigned char* out, const FrameArgs& fa, hipStream_t stream) {
+    const size_t npix = (size_t)fa.width * (size_t)fa.rows;
+    hipLaunchKernelGGL(tonemap_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, stream, fb, reinterpret_cast<uchar4*>(out), fa);
 }
 void launch_count(const DevState& S, size_t n, unsigned spp, unsigned long long* out3, hipStream_t stream) {
     unsigned blocks = (unsigned)((n + 255) / 256);

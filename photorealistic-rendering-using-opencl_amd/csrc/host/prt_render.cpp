@@ -5,6 +5,7 @@
 // GLFW loop replaced by "-frames N" or "-spp N" and PrtSc replaced by "-out file.pfm".
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -22,11 +23,55 @@ static bool write_pfm(const std::string& path, const std::vector<float>& rgba, i
     if (!f) return false;
     std::fprintf(f, "PF\n%d %d\n-1.0\n", w, h);
     std::vector<float> row((size_t)w * 3);
-    for (int y = h - 1; y >= 0; --y) {               // PFM is bottom-up; framebuffer row 0 is the top
+    for (int y = 0; y < h; ++y) {                    // PFM is bottom-up, and so is the framebuffer (row 0 = lowest scan line)
         for (int x = 0; x < w; ++x)
             for (int c = 0; c < 3; ++c) row[(size_t)x * 3 + c] = rgba[((size_t)y * w + x) * 4 + c];
         std::fwrite(row.data(), sizeof(float), row.size(), f);
     }
+    std::fclose(f);
+    return true;
+}
+
+// PNG with stored (uncompressed) deflate blocks: no zlib needed.  `rgba` bottom-up, PNG rows are top-down
+// (the reference flips on write too, include/GL/cl_gl_interop.h:139).
+static bool write_png(const std::string& path, const std::vector<uint8_t>& rgba, int w, int h) {
+    static uint32_t crc_table[256];
+    static bool have_table = false;
+    if (!have_table) {
+        for (uint32_t n = 0; n < 256; ++n) { uint32_t c = n; for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1; crc_table[n] = c; }
+        have_table = true;
+    }
+    auto crc = [&](const std::vector<uint8_t>& d) { uint32_t c = 0xFFFFFFFFu; for (uint8_t b : d) c = crc_table[(c ^ b) & 0xFF] ^ (c >> 8); return c ^ 0xFFFFFFFFu; };
+    auto be32 = [](std::vector<uint8_t>& v, uint32_t x) { v.push_back(x >> 24); v.push_back(x >> 16); v.push_back(x >> 8); v.push_back(x); };
+    FILE* f = std::fopen(path.c_str(), "wb");
+    if (!f) return false;
+    auto chunk = [&](const char* type, const std::vector<uint8_t>& data) {
+        std::vector<uint8_t> len; be32(len, (uint32_t)data.size());
+        std::vector<uint8_t> td(type, type + 4); td.insert(td.end(), data.begin(), data.end());
+        std::vector<uint8_t> c; be32(c, crc(td));
+        std::fwrite(len.data(), 1, 4, f); std::fwrite(td.data(), 1, td.size(), f); std::fwrite(c.data(), 1, 4, f);
+    };
+    const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    std::fwrite(sig, 1, 8, f);
+    std::vector<uint8_t> ihdr; be32(ihdr, (uint32_t)w); be32(ihdr, (uint32_t)h);
+    ihdr.insert(ihdr.end(), {8, 6, 0, 0, 0});                     // 8 bit, RGBA
+    chunk("IHDR", ihdr);
+    std::vector<uint8_t> raw;
+    raw.reserve((size_t)h * ((size_t)w * 4 + 1));
+    for (int y = h - 1; y >= 0; --y) { raw.push_back(0); raw.insert(raw.end(), rgba.begin() + (size_t)y * w * 4, rgba.begin() + (size_t)(y + 1) * w * 4); }
+    std::vector<uint8_t> z = {0x78, 0x01};
+    uint32_t a = 1, b = 0;
+    for (size_t off = 0; off < raw.size();) {
+        const size_t n = std::min<size_t>(65535, raw.size() - off);
+        z.push_back(off + n == raw.size() ? 1 : 0);
+        z.push_back(n & 0xFF); z.push_back(n >> 8); z.push_back(~n & 0xFF); z.push_back((~n >> 8) & 0xFF);
+        z.insert(z.end(), raw.begin() + off, raw.begin() + off + n);
+        for (size_t i = off; i < off + n; ++i) { a = (a + raw[i]) % 65521u; b = (b + a) % 65521u; }
+        off += n;
+    }
+    be32(z, (b << 16) | a);
+    chunk("IDAT", z);
+    chunk("IEND", {});
     std::fclose(f);
     return true;
 }
@@ -111,7 +156,16 @@ int main(int argc, char** argv) {
         CHECK(prt_query_counts(ctx, frames ? 0 : spp, &st));
         std::printf("%dx%d: %llu samples, %llu segments, %.1f ms on the device (%u launches)\n", window_width, window_height,
                     (unsigned long long)st.samples, (unsigned long long)st.segments, st.kernel_ms, st.launches);
-        if (!write_pfm(out_path, rgba, window_width, window_height)) { std::fprintf(stderr, "cannot write %s\n", out_path.c_str()); return 1; }
+        const bool png = out_path.size() > 4 && out_path.compare(out_path.size() - 4, 4, ".png") == 0;
+        bool ok;
+        if (png) {                                                 // encoder 0 of the reference: the tonemapped picture
+            std::vector<uint8_t> ldr((size_t)window_width * window_height * 4);
+            CHECK(prt_tonemap_rgba8(ctx, ldr.data()));
+            ok = write_png(out_path, ldr, window_width, window_height);
+        } else {                                                   // encoder 1: the linear picture
+            ok = write_pfm(out_path, rgba, window_width, window_height);
+        }
+        if (!ok) { std::fprintf(stderr, "cannot write %s\n", out_path.c_str()); return 1; }
     } catch (const std::exception& e) {
         std::fprintf(stderr, "error: %s\n", e.what());
         if (ctx) prt_destroy(ctx);

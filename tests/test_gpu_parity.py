@@ -310,3 +310,50 @@ def test_axis_parallel_rays_nan_slabs(prt, oracle):
     ostate, oimg = oracle.Restatement().render(cfg, scene.desc, cam, W, H, seeds, threads=8)
     _assert_same(oracle, ostate, oimg, r.read_state(), r.read_framebuffer(), "axis-parallel rays")
     r.close()
+
+
+def test_tonemap_matches_the_reference_shader_and_cli_writes_png(prt, oracle, tmp_path):
+    """display side (row N3): shaders/tonemapper.glsl evaluated in float64 numpy vs prt_tonemap_rgba8 (+-1 LSB),
+    and the headless CLI (the main.cpp equivalent) end to end: render -> tonemap -> PNG"""
+    import struct
+    import subprocess
+    import zlib
+    W, H = 96, 64
+    scene, cfg, cam, env, r = _setup(prt, "cornell_coat", W, H)
+    r.render_spp(4, prt.seed_pairs(4 * cfg.max_bounces + 64))
+    fb = r.read_framebuffer().astype(np.float64)
+    ldr = r.tonemap_rgba8()
+    r.close()
+    yy, xx = np.mgrid[0:H, 0:W]
+    px, py = 1 - 2 * (xx + 0.5) / W, 1 - 2 * (yy + 0.5) / H
+    vig = (1.25 / (1.1 + 1.1 * (px * px + py * py))) ** 2
+    sm = lambda e0, e1, x: (lambda t: t * t * (3 - 2 * t))(np.clip((x - e0) / (e1 - e0), 0, 1))
+    vig = 0.75 + 0.25 * sm(0.1, 1.1, vig)
+    curve = lambda x: (57.25 * x * x) / (57.25 * x * x + x + 56.25)
+    col = curve(fb[..., :3] * vig[..., None]) / curve(1.2)
+    col = np.clip(sm(-0.025, 1.0, col) ** (1 / 2.2), 0, 1)
+    want = np.rint(col * 255)
+    assert np.abs(ldr[..., :3].astype(np.float64) - want).max() <= 1 and (ldr[..., 3] == 255).all()
+    # CLI
+    exe = os.path.join(os.path.dirname(prt.__file__), "prt_render")
+    out = tmp_path / "render.png"
+    res = subprocess.run([exe, "-scene", os.path.join(prt.SCENES_DIR, "cornell_coat.json"), "-models", prt.MODELS_DIR + "/",
+                          "-width", str(W), "-height", str(H), "-spp", "4", "-out", str(out)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert res.returncode == 0, res.stdout
+    raw = out.read_bytes()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, dims = 8, b"", None
+    while pos < len(raw):
+        n, typ = struct.unpack(">I4s", raw[pos:pos + 8])
+        data = raw[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", raw[pos + 8 + n:pos + 12 + n])[0] == (zlib.crc32(typ + data) & 0xffffffff)
+        if typ == b"IHDR":
+            dims = struct.unpack(">II", data[:8])
+        if typ == b"IDAT":
+            idat += data
+        pos += 12 + n
+    assert dims == (W, H)
+    pix = np.frombuffer(zlib.decompress(idat), dtype=np.uint8).reshape(H, W * 4 + 1)
+    assert (pix[:, 0] == 0).all()
+    png = pix[:, 1:].reshape(H, W, 4)
+    assert np.array_equal(png[::-1], ldr)             # the PNG is top-down, the framebuffer bottom-up; same render (deterministic)
