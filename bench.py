@@ -197,6 +197,9 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(prt, a)
+            ref = cpu_reference_build(prt, a)
+            if ref is not None:
+                out["cpu_reference_build"] = ref
         print(json.dumps(out))
     r.close()
     if world > 1:
@@ -228,6 +231,36 @@ def cpu_baseline(prt, a):
     return {"value": round(W * H * spp / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
             "sample": "%dx%d %dspp of the same scene and camera (oracle/pt_oracle.c, %d threads, %.1f s)" % (W, H, spp, cores, dt),
             "gsegments_per_s": round(float(state["acc"][:, 3].sum()) / dt / 1e9, 5)}
+
+
+def cpu_reference_build(prt, a):
+    """the reference's OWN kernel text compiled for the host (oracle/_ref, built in the development container
+    and shipped as a binary) on a smaller sample of the same workload; None if that build is not present"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_api as O
+    variant = os.path.splitext(a.scene)[0]
+    if a.phase != "isotropic":
+        variant += "_" + a.phase
+    if not O.ref_available(variant):
+        return None
+    W, H, spp = 480, 270, 48
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 64))
+    scene = prt.HostScene(a.scene)
+    cfg = scene.config()
+    cam = prt.default_camera(W, H)
+    seeds = prt.seed_pairs(spp * max(cfg.max_bounces, 8) + 64)
+    env = prt.make_sky(1024, 512) if a.env == "sky" else None
+    t0 = time.perf_counter()
+    state, _ = O.RefOracle(variant).render(scene.desc, bytes(cam), W, H, seeds, env=env, spp_limit=spp, threads=cores)
+    dt = time.perf_counter() - t0
+    if not (state["samples"] == spp).all():
+        return None
+    return {"value": round(W * H * spp / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "reference",
+            "sample": "%dx%d %dspp of the same scene and camera (reference kernel text, clang x86-64 + prt_detmath, %d threads, %.1f s)" % (W, H, spp, cores, dt)}
 
 
 if __name__ == "__main__":
