@@ -35,7 +35,7 @@ typedef enum prt_status {
     PRT_ERR_NO_DEVICE = -2,
     PRT_ERR_HIP = -3,
     PRT_ERR_NOT_READY = -4,     /* scene / camera / size not set before rendering */
-    PRT_ERR_UNSUPPORTED = -5    /* scene needs a feature outside the hot-path scope (SDF, box) */
+    PRT_ERR_UNSUPPORTED = -5    /* box primitives: they never render in the reference either (box.cl is not included) */
 } prt_status;
 
 /* phase function of the global medium.  The reference wires Isotropic at source level
@@ -54,8 +54,8 @@ typedef struct prt_config {
     int32_t max_spec_bounces;        /* :133-140              MAX_SPEC_BOUNCES       (4)  */
     int32_t max_trans_bounces;       /* :142-149              MAX_TRANS_BOUNCES      (12) */
     int32_t max_scattering_events;   /* :151-158              MAX_SCATTERING_EVENTS  (12) */
-    int32_t marching_steps;          /* :160-167  accepted, unused: SDF primitives are out of scope */
-    int32_t shadow_marching_steps;   /* :169-176  accepted, unused */
+    int32_t marching_steps;          /* :160-167  MARCHING_STEPS of the raymarched SDF primitives (128) */
+    int32_t shadow_marching_steps;   /* :169-176  SHADOW_MARCHING_STEPS (64) */
     uint32_t active_mats;            /* :226-345  ACTIVE_MATS: OR of all material type bits in the scene */
     uint32_t geom_flags;             /* :180-222  PRT_GEOM_* bits for H_SPHERE/H_BOX/H_SDF/H_QUAD */
     uint32_t light_count;            /* :367-400  LIGHT_COUNT */

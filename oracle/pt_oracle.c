@@ -377,6 +377,63 @@ static float quad_directPdf(v3 dir, const prt_mesh* plane, v3 p) {
     return t * t / (cosTheta * area);
 }
 
+/* ---- kernels/geometry/sdf.cl:5-118 (raymarched primitives; host type bits include/Scene/geometry.h:15-19) ---- */
+#define SDF_SPHERE (1 << 4)
+#define SDF_BOX (1 << 5)
+#define SDF_ROUND_BOX (1 << 6)
+#define SDF_PLANE (1 << 7)
+static inline v3 vabs(v3 a) { return V(prt_fabs(a.x), prt_fabs(a.y), prt_fabs(a.z)); }
+static inline v3 vmax0(v3 a) { return V(prt_fmax(a.x, 0.0f), prt_fmax(a.y, 0.0f), prt_fmax(a.z, 0.0f)); }
+static float s_map(const prt_mesh* sdf, v3 pos) {
+    const v3 c = vsub(pos, vload(sdf->pos));
+    const v3 b = vload(sdf->joker);
+    if (sdf->t & SDF_SPHERE) return vlength(c) - sdf->joker[0];
+    else if (sdf->t & SDF_BOX) {
+        v3 d = vsub(vabs(c), b);
+        return prt_fmin(prt_fmax(d.x, prt_fmax(d.y, d.z)), 0.0f) + vlength(vmax0(d));
+    } else if (sdf->t & SDF_ROUND_BOX) return vlength(vmax0(vsub(vabs(c), b))) - sdf->joker[3];
+    else if (sdf->t & SDF_PLANE) return vdot(c, b) + sdf->joker[3];
+    return INF;
+}
+static float sdf_map(const Scene* sc, float tmin, v3 pos, int* mesh_id) {
+    float dist = tmin;
+    const uint32_t fl = sc->counts[0] + sc->counts[1];
+    for (uint32_t i = sc->counts[0]; i < fl; ++i) {
+        float temp_dist = s_map(&sc->meshes[i], pos);
+        if (temp_dist < dist) { dist = temp_dist; *mesh_id = (int)i; }
+    }
+    return dist;
+}
+static v3 calcNormal(const prt_mesh* mesh, v3 pos) {
+    const float e = EPS * 2.0f;
+    return vnormalize(V(s_map(mesh, vadd(pos, V(e, 0, 0))) - s_map(mesh, vsub(pos, V(e, 0, 0))),
+                        s_map(mesh, vadd(pos, V(0, e, 0))) - s_map(mesh, vsub(pos, V(0, e, 0))),
+                        s_map(mesh, vadd(pos, V(0, 0, e))) - s_map(mesh, vsub(pos, V(0, 0, e)))));
+}
+static int shadow_sdf(const Scene* sc, const Ray* ray) {
+    float t = EPS * 100.0f;
+    int id = -1;
+    for (int i = 0; i < sc->cfg->shadow_marching_steps; ++i) {
+        float h = prt_fabs(sdf_map(sc, ray->t, vadd(ray->origin, vscale(ray->dir, t)), &id));
+        t += h;
+        if (h < EPS || t > ray->t) break;
+    }
+    return t <= ray->t;
+}
+static int intersect_sdf(const Scene* sc, Ray* ray, int* mesh_id) {
+    float t = EPS * 10.0f;
+    int id = -1;                /* the reference leaves it uninitialised; it is always set when the march succeeds */
+    for (int i = 0; i < sc->cfg->marching_steps; ++i) {
+        float h = prt_fabs(sdf_map(sc, ray->t, vadd(ray->origin, vscale(ray->dir, t)), &id));
+        if (h < EPS || t > ray->t) break;
+        t += h;
+    }
+    if (t > ray->t) return 0;
+    ray->t = t;
+    *mesh_id = id;
+    return 1;
+}
+
 /* ---- kernels/geometry/geometry.cl:11-52 ---- */
 static int sampleDirect(const Scene* sc, const prt_mesh* mesh, v3 p, LightSample* s, Rng* rng) {
     if ((sc->cfg->geom_flags & PRT_GEOM_SPHERE) && (mesh->t & PRT_GEOM_SPHERE)) return sphere_sampleDirect(mesh, p, s, rng);
@@ -406,8 +463,14 @@ static int intersect_scene(Scene* sc, Ray* ray, int* mesh_id) {
             }
         }
     }
+    if ((sc->cfg->geom_flags & PRT_GEOM_SDF) && sc->counts[1]) {          /* intersect.cl:185-194 */
+        if (intersect_sdf(sc, ray, mesh_id)) {
+            ray->pos = vadd(ray->origin, vscale(ray->dir, ray->t));
+            ray->normal = calcNormal(&sc->meshes[*mesh_id], ray->pos);
+        }
+    }
     /* boxes: geometry/box.cl is never #FILE-included, so __BOX__ is never defined (geometry.cl:4-9);
-     * scenes with boxes or SDFs are rejected by pto_render */
+     * scenes with boxes are rejected by pto_render */
     if (sc->cfg->geom_flags & PRT_GEOM_QUAD) {
         uint32_t fl = sc->counts[0] + sc->counts[1];
         for (uint32_t i = 0; i < sc->counts[3]; ++i) {
@@ -430,6 +493,9 @@ static int shadow(Scene* sc, Ray* ray) {
     if (sc->cfg->geom_flags & PRT_GEOM_SPHERE) {
         for (uint32_t i = 0; i < sc->counts[0]; ++i)
             if (intersect_sphere(ray, &sc->meshes[i])) { if (ray->t < maxDist) return 0; }
+    }
+    if ((sc->cfg->geom_flags & PRT_GEOM_SDF) && sc->counts[1]) {          /* intersect.cl:119-126 */
+        if (shadow_sdf(sc, ray)) return 0;
     }
     uint32_t fl = sc->counts[0] + sc->counts[1];
     if (sc->cfg->geom_flags & PRT_GEOM_QUAD) {
@@ -1200,7 +1266,7 @@ int pto_render(const pto_job* j, pto_diag* diag) {
     if (!j || !j->cfg || !j->scene || !j->camera || !j->state || !j->out_rgba) return -1;
     const prt_scene_desc* d = j->scene;
     const uint32_t n_meshes = d->object_count[7];
-    if (d->object_count[1] || d->object_count[2]) return -5;         /* SDF / box: out of scope */
+    if (d->object_count[2]) return -5;                               /* boxes: geometry/box.cl is dead code in the reference */
     prt_mesh* guarded = (prt_mesh*)calloc((size_t)n_meshes + 1, sizeof(prt_mesh));   /* [0] = zero guard (Q6) */
     if (!guarded) return -2;
     if (n_meshes) memcpy(guarded + 1, d->meshes, (size_t)n_meshes * sizeof(prt_mesh));

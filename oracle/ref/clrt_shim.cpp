@@ -103,6 +103,9 @@ float3 shim_fract3(float3 v, float3* ip) {
     *ip = float3{prt_floor(v.x), prt_floor(v.y), prt_floor(v.z)};
     return V3(prt_fract);
 }
+float3 fabs(float3 v) { return V3(prt_fabs); }
+float3 fmax(float3 a, float b) { return float3{prt_fmax(a.x, b), prt_fmax(a.y, b), prt_fmax(a.z, b)}; }
+float fast_length(float2 v) { return prt_sqrt(v.x * v.x + v.y * v.y); }
 float dot(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 float dot(float2 a, float2 b) { return a.x * b.x + a.y * b.y; }
 float3 cross(float3 a, float3 b) {

@@ -28,7 +28,7 @@ struct prt_ctx {
     // scene
     DevScene sc{};
     void* d_pairs = nullptr; void* d_tri_geom = nullptr; void* d_tri_nrm = nullptr;
-    void* d_spheres = nullptr; void* d_quads = nullptr; void* d_mats = nullptr; void* d_env = nullptr;
+    void* d_spheres = nullptr; void* d_quads = nullptr; void* d_sdfs = nullptr; void* d_mats = nullptr; void* d_env = nullptr;
     bool have_scene = false, have_cam = false, have_size = false;
     DevCamera cam{};
     // frame
@@ -71,8 +71,8 @@ extern "C" int prt_create(int device, const prt_config* cfg, prt_ctx** out) {
     }
     if (device < 0 || device >= n) { g_global_error = "prt_create: device ordinal out of range"; return PRT_ERR_INVALID_ARGUMENT; }
     if (cfg->light_count > PRT_MAX_LIGHTS) { g_global_error = "prt_create: too many lights"; return PRT_ERR_INVALID_ARGUMENT; }
-    if (cfg->geom_flags & (PRT_GEOM_SDF | PRT_GEOM_BOX)) {
-        g_global_error = "prt_create: SDF / box primitives are outside the hot-path scope (SURVEY.md s2 row 4b)";
+    if (cfg->geom_flags & PRT_GEOM_BOX) {
+        g_global_error = "prt_create: box primitives never render in the reference (geometry/box.cl is not included, SURVEY.md s9-Q10)";
         return PRT_ERR_UNSUPPORTED;
     }
     prt_ctx* c = new prt_ctx();
@@ -128,7 +128,7 @@ static int alloc_wave(prt_ctx* c) {
 
 static void free_scene(prt_ctx* c) {
     free_dev(c->d_pairs); free_dev(c->d_tri_geom); free_dev(c->d_tri_nrm);
-    free_dev(c->d_spheres); free_dev(c->d_quads); free_dev(c->d_mats);
+    free_dev(c->d_spheres); free_dev(c->d_quads); free_dev(c->d_sdfs); free_dev(c->d_mats);
 }
 
 extern "C" void prt_destroy(prt_ctx* c) {
@@ -171,8 +171,9 @@ extern "C" int prt_upload_scene(prt_ctx* c, const prt_scene_desc* s) {
     HIPCHK(c, hipSetDevice(c->device));
     const uint32_t n_sph = s->object_count[0], n_sdf = s->object_count[1], n_box = s->object_count[2], n_quad = s->object_count[3];
     const uint32_t n_mesh = s->object_count[7];
-    if (n_sdf || n_box) return fail(c, PRT_ERR_UNSUPPORTED, "prt_upload_scene: SDF / box primitives are outside the hot-path scope");
-    if (n_sph + n_quad != n_mesh) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: object_count does not add up");
+    if (n_box) return fail(c, PRT_ERR_UNSUPPORTED, "prt_upload_scene: box primitives never render in the reference (box.cl is dead code)");
+    if (n_sph + n_sdf + n_quad != n_mesh) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: object_count does not add up");
+    if (n_sdf && !(c->cfg.geom_flags & PRT_GEOM_SDF)) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: SDF meshes but the config has no H_SDF");
     if (n_mesh && !s->meshes) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: meshes is null");
     const uint32_t T = s->triangle_count, N = s->bvh_node_count;
     if (T && (!s->vertices || !s->normals || !s->primitive_indices || !s->bvh_nodes || !N))
@@ -181,6 +182,7 @@ extern "C" int prt_upload_scene(prt_ctx* c, const prt_scene_desc* s) {
     // ---- primitives + materials
     std::vector<DevSphere> spheres(n_sph);
     std::vector<DevQuad> quads(n_quad);
+    std::vector<DevSdf> sdfs(n_sdf);
     std::vector<DevMaterial> mats(n_mesh + 2);
     std::memset(mats.data(), 0, mats.size() * sizeof(DevMaterial));
     for (uint32_t i = 0; i < n_mesh; ++i) {
@@ -190,9 +192,14 @@ extern "C" int prt_upload_scene(prt_ctx* c, const prt_scene_desc* s) {
             if (!(m.t & PRT_GEOM_SPHERE)) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: mesh order/type mismatch (sphere expected)");
             DevSphere& d = spheres[i];
             d.pos[0] = m.pos[0]; d.pos[1] = m.pos[1]; d.pos[2] = m.pos[2]; d.radius = m.joker[0];
+        } else if (i < n_sph + n_sdf) {
+            if (!(m.t & PRT_GEOM_SDF)) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: mesh order/type mismatch (sdf expected)");
+            DevSdf& d = sdfs[i - n_sph];
+            d.pos[0] = m.pos[0]; d.pos[1] = m.pos[1]; d.pos[2] = m.pos[2]; d.type = m.t;
+            for (int k = 0; k < 4; ++k) d.params[k] = m.joker[k];
         } else {
             if (!(m.t & PRT_GEOM_QUAD)) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: mesh order/type mismatch (quad expected)");
-            DevQuad& d = quads[i - n_sph];
+            DevQuad& d = quads[i - n_sph - n_sdf];
             std::memset(&d, 0, sizeof(d));
             for (int k = 0; k < 3; ++k) { d.base[k] = m.joker[k]; d.edge0[k] = m.joker[3 + k]; d.edge1[k] = m.joker[6 + k]; d.normal[k] = m.joker[9 + k]; }
             d.area = m.joker[12];
@@ -298,7 +305,8 @@ extern "C" int prt_upload_scene(prt_ctx* c, const prt_scene_desc* s) {
     (void)hipStreamSynchronize(c->stream);
     int rc;
     if ((rc = upload(c, c->d_pairs, pairs)) || (rc = upload(c, c->d_tri_geom, tg)) || (rc = upload(c, c->d_tri_nrm, tn)) ||
-        (rc = upload(c, c->d_spheres, spheres)) || (rc = upload(c, c->d_quads, quads)) || (rc = upload(c, c->d_mats, mats)))
+        (rc = upload(c, c->d_spheres, spheres)) || (rc = upload(c, c->d_quads, quads)) || (rc = upload(c, c->d_sdfs, sdfs)) ||
+        (rc = upload(c, c->d_mats, mats)))
         return rc;
 
     sc.pairs = static_cast<const NodePair*>(c->d_pairs);
@@ -307,15 +315,19 @@ extern "C" int prt_upload_scene(prt_ctx* c, const prt_scene_desc* s) {
     sc.tri_nrm = static_cast<const TriNrm*>(c->d_tri_nrm);
     sc.spheres = static_cast<const DevSphere*>(c->d_spheres);
     sc.quads = static_cast<const DevQuad*>(c->d_quads);
+    sc.sdfs = static_cast<const DevSdf*>(c->d_sdfs);
     sc.mats = static_cast<const DevMaterial*>(c->d_mats);
-    sc.n_spheres = n_sph; sc.n_quads = n_quad; sc.quad_mesh_base = n_sph; sc.n_meshes = n_mesh;
+    sc.n_spheres = n_sph; sc.n_quads = n_quad; sc.quad_mesh_base = n_sph + n_sdf; sc.n_meshes = n_mesh; sc.n_sdfs = n_sdf;
+    sc.marching_steps = c->cfg.marching_steps; sc.shadow_marching_steps = c->cfg.shadow_marching_steps;
     sc.light_sphere = sc.light_quad = 0xFFFFFFFFu; sc.light_mesh = 0;
     const prt_config& cfg = c->cfg;
     if (cfg.light_count) {
         const uint32_t li = cfg.light_indices[0];
         if (li >= n_mesh) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: light index out of range");
         sc.light_mesh = li;
-        if (li < n_sph) sc.light_sphere = li; else sc.light_quad = li - n_sph;
+        if (li < n_sph) sc.light_sphere = li;
+        else if (li >= n_sph + n_sdf) sc.light_quad = li - n_sph - n_sdf;
+        // an SDF light cannot be sampled (kernels/geometry/geometry.cl:11-32 returns false): both stay unset
     }
     sc.active_mats = cfg.active_mats; sc.geom_flags = cfg.geom_flags;
     sc.max_bounces = cfg.max_bounces; sc.max_diff_bounces = cfg.max_diff_bounces; sc.max_spec_bounces = cfg.max_spec_bounces;

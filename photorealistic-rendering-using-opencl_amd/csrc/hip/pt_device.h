@@ -344,8 +344,61 @@ PT_DEV bool hit_quad(const DevQuad& qd, const Ray& ray, float& best_t, f3& q_out
     return true;
 }
 
+// ---- raymarched SDF primitives, kernels/geometry/sdf.cl:5-118 ("next" row N4) ---------------------------
+PT_DEV f3 vabs3(f3 a) { return F3(prt_fabs(a.x), prt_fabs(a.y), prt_fabs(a.z)); }
+PT_DEV f3 vmax0(f3 a) { return F3(prt_fmax(a.x, 0.0f), prt_fmax(a.y, 0.0f), prt_fmax(a.z, 0.0f)); }
+PT_DEV float s_map(const DevSdf& sdf, f3 pos) {
+    const f3 c = pos - ld3(sdf.pos);
+    const f3 b = ld3(sdf.params);
+    if (sdf.type & (1u << 4)) return length(c) - sdf.params[0];                                 // SDF_SPHERE
+    else if (sdf.type & (1u << 5)) {                                                              // SDF_BOX
+        f3 d = vabs3(c) - b;
+        return prt_fmin(prt_fmax(d.x, prt_fmax(d.y, d.z)), 0.0f) + length(vmax0(d));
+    } else if (sdf.type & (1u << 6)) return length(vmax0(vabs3(c) - b)) - sdf.params[3];         // SDF_ROUND_BOX
+    else if (sdf.type & (1u << 7)) return dot(c, b) + sdf.params[3];                             // SDF_PLANE
+    return PT_INF;
+}
+PT_DEV float sdf_map(const DevScene& sc, float tmin, f3 pos, int& id) {
+    float dist = tmin;
+    for (unsigned i = 0; i < sc.n_sdfs; ++i) {
+        const float temp_dist = s_map(sc.sdfs[i], pos);
+        if (temp_dist < dist) { dist = temp_dist; id = (int)(sc.n_spheres + i); }
+    }
+    return dist;
+}
+PT_DEV f3 sdf_normal(const DevSdf& m, f3 pos) {
+    const float e = PT_EPS * 2.0f;
+    return normalize(F3(s_map(m, pos + F3(e, 0, 0)) - s_map(m, pos - F3(e, 0, 0)),
+                        s_map(m, pos + F3(0, e, 0)) - s_map(m, pos - F3(0, e, 0)),
+                        s_map(m, pos + F3(0, 0, e)) - s_map(m, pos - F3(0, 0, e))));
+}
+PT_DEV bool shadow_sdf(const DevScene& sc, const f3 o, const f3 d, const float tmax) {
+    float t = PT_EPS * 100.0f;
+    int id = -1;
+    for (int i = 0; i < sc.shadow_marching_steps; ++i) {
+        const float h = prt_fabs(sdf_map(sc, tmax, o + d * t, id));
+        t += h;
+        if (h < PT_EPS || t > tmax) break;
+    }
+    return t <= tmax;
+}
+PT_DEV bool intersect_sdf(const DevScene& sc, const Ray& ray, float& best_t, int& mesh_id) {
+    float t = PT_EPS * 10.0f;
+    int id = -1;
+    for (int i = 0; i < sc.marching_steps; ++i) {
+        const float h = prt_fabs(sdf_map(sc, best_t, ray.origin + ray.dir * t, id));
+        if (h < PT_EPS || t > best_t) break;
+        t += h;
+    }
+    if (t > best_t) return false;
+    best_t = t;
+    mesh_id = id;
+    return true;
+}
+
 // ---- the rest of intersect_scene, kernels/intersect.cl:167-236, given the BVH result ----------------
 // in: ray.origin/dir/normal + traversal result.  out: ray.t/normal/pos/backside, mesh_id (-1 = OBJ or nothing).
+template <bool SDF>
 PT_DEV bool finish_closest(const DevScene& sc, Ray& ray, const TravRes& tr, int& mesh_id) {
     float t = tr.t;
     mesh_id = -1;
@@ -364,6 +417,12 @@ PT_DEV bool finish_closest(const DevScene& sc, Ray& ray, const TravRes& tr, int&
                 ray.normal = normalize(ray.pos - ld3(s.pos));
                 mesh_id = (int)i;
             }
+        }
+    }
+    if (SDF && sc.n_sdfs) {                                                                  // intersect.cl:185-194
+        if (intersect_sdf(sc, ray, t, mesh_id)) {
+            ray.pos = ray.origin + ray.dir * t;
+            ray.normal = sdf_normal(sc.sdfs[mesh_id - (int)sc.n_spheres], ray.pos);
         }
     }
     if (sc.geom_flags & PRT_GEOM_QUAD) {
@@ -386,6 +445,7 @@ PT_DEV bool finish_closest(const DevScene& sc, Ray& ray, const TravRes& tr, int&
 }
 
 // ---- the rest of shadow(), kernels/intersect.cl:108-151, given that the BVH did not occlude: true = unoccluded
+template <bool SDF>
 PT_DEV bool finish_shadow(const DevScene& sc, const f3 origin, const f3 dir, const float maxDist) {
     Ray ray;
     ray.origin = origin; ray.dir = dir;
@@ -394,6 +454,7 @@ PT_DEV bool finish_shadow(const DevScene& sc, const f3 origin, const f3 dir, con
         for (unsigned i = 0; i < sc.n_spheres; ++i)
             if (hit_sphere(sc.spheres[i], ray, t)) return false;     // an accepted hit always has t < maxDist
     }
+    if (SDF && sc.n_sdfs && shadow_sdf(sc, origin, dir, maxDist)) return false;                     // intersect.cl:119-126
     if (sc.geom_flags & PRT_GEOM_QUAD) {
         for (unsigned i = 0; i < sc.n_quads; ++i) {
             f3 q;
@@ -809,9 +870,11 @@ PT_DEV float coat_pdf(const Event& e, const Mat& mat) {
     return rough_conductor_pdf(nwi, nwo, mat) * (1.0f - specularProbability) * eta * eta * prt_fabs(e.wo.z / cosThetaTo);
 }
 
-// ---- dispatch, kernels/bxdf/bxdf.cl:57-273.  MATS = compile-time ACTIVE_MATS (0 = run-time) ---------
+// ---- dispatch, kernels/bxdf/bxdf.cl:57-273.  MATS = compile-time ACTIVE_MATS (0 = run-time); the
+// PT_MATS_SDF bit marks the variants that carry the raymarched primitives (H_SDF scenes only) ---------
+#define PT_MATS_SDF 0x80000000u
 template <unsigned MATS>
-PT_DEV unsigned active_mats(const DevScene& sc) { return MATS ? MATS : sc.active_mats; }
+PT_DEV unsigned active_mats(const DevScene& sc) { return (MATS & ~PT_MATS_SDF) ? (MATS & ~PT_MATS_SDF) : sc.active_mats; }
 
 template <unsigned MATS>
 PT_DEV bool bsdf_sample2(const DevScene& sc, Event& e, const Ray& ray, const Mat& mat, Rng& rng) {
@@ -1049,7 +1112,7 @@ PT_DEV TravReq seg_after_w1(const DevScene& sc, SegCtx& c, Path& st, const TravR
         didHit = st.hc.didHit; c.mesh_id = st.hc.mesh_id;
         ray.t = st.hc.t; ray.normal = st.hc.normal; ray.pos = st.hc.pos; ray.backside = st.hc.backside;
     } else {
-        didHit = finish_closest(sc, ray, r1, c.mesh_id);
+        didHit = finish_closest<(MATS & PT_MATS_SDF) != 0>(sc, ray, r1, c.mesh_id);
     }
     st.hc.valid = false;
     const Mat mat = load_mat((c.mesh_id + 1) ? &sc.mats[c.mesh_id + 1] : &sc.mats[sc.n_meshes + 1]);
@@ -1129,7 +1192,7 @@ PT_DEV TravReq seg_after_w2(const DevScene& sc, SegCtx& c, Path& st, const bool 
         const Mat mat = load_mat((c.mesh_id + 1) ? &sc.mats[c.mesh_id + 1] : &sc.mats[sc.n_meshes + 1]);
         if (w2_ran) {                                                    // the probe ray, base.cl:54-75
             int mid;
-            const bool hit2 = finish_closest(sc, ray, r2, mid);
+            const bool hit2 = finish_closest<(MATS & PT_MATS_SDF) != 0>(sc, ray, r2, mid);
             st.hc.valid = true; st.hc.didHit = hit2; st.hc.backside = ray.backside; st.hc.t = ray.t; st.hc.mesh_id = mid;
             st.hc.normal = ray.normal; st.hc.pos = ray.pos;
             if (hit2) {
@@ -1159,7 +1222,7 @@ PT_DEV TravReq seg_after_w2(const DevScene& sc, SegCtx& c, Path& st, const bool 
         sRay.origin = c.ms_p; sRay.dir = c.ps.w; sRay.normal = splat(0.0f); sRay.pos = splat(0.0f); sRay.backside = false;
         sRay.t = PT_INF; sRay.time = 0.0f;
         int mid;
-        const bool hit3 = finish_closest(sc, sRay, r2, mid);
+        const bool hit3 = finish_closest<(MATS & PT_MATS_SDF) != 0>(sc, sRay, r2, mid);
         st.hc.valid = true; st.hc.didHit = hit3; st.hc.backside = sRay.backside; st.hc.t = sRay.t; st.hc.mesh_id = mid;
         st.hc.normal = sRay.normal; st.hc.pos = sRay.pos;
         if (hit3) {
@@ -1176,7 +1239,7 @@ PT_DEV TravReq seg_after_w2(const DevScene& sc, SegCtx& c, Path& st, const bool 
     // shadow(), intersect.cl:94-152: BVH, sphere and quad tests are independent and the any-hit walk never
     // shrinks ray.t, so the boolean does not depend on their order: the 7 primitives first.
     if (c.sh) {
-        if (finish_shadow(sc, c.sh_o, c.sh_d, c.sh_tmax)) rq3.want = true;
+        if (finish_shadow<(MATS & PT_MATS_SDF) != 0>(sc, c.sh_o, c.sh_d, c.sh_tmax)) rq3.want = true;
         else c.sh = false;                                               // occluded by a primitive
     }
     return rq3;

@@ -483,6 +483,11 @@ const char* launch_render(const DevScene& sc, const DevCamera& cam, const DevSta
                           hipStream_t stream) {
     constexpr unsigned LD = PRT_MAT_LIGHT | PRT_MAT_DIFF;
     const unsigned am = sc.active_mats;
+    if (sc.n_sdfs) {                      // H_SDF scenes: the generic variants that carry the raymarcher
+        if (!sc.has_medium) { launch_variant<PT_MATS_SDF, false>(sc, cam, S, fa, fb, stream); return "render_kernel<generic,sdf>"; }
+        launch_variant<PT_MATS_SDF, true>(sc, cam, S, fa, fb, stream);
+        return "render_kernel<generic,sdf,medium>";
+    }
     if (!sc.has_medium) {
         if (am == LD) { launch_variant<LD, false>(sc, cam, S, fa, fb, stream); return "render_kernel<LIGHT|DIFF>"; }
         launch_variant<0u, false>(sc, cam, S, fa, fb, stream);
@@ -503,7 +508,10 @@ void launch_wf_pass(const DevScene& sc, const DevCamera& cam, const DevState& S,
                     unsigned pass, unsigned trav_blocks, hipStream_t stream) {
     constexpr unsigned LD = PRT_MAT_LIGHT | PRT_MAT_DIFF;
     const unsigned am = sc.active_mats;
-    if (!sc.has_medium) {
+    if (sc.n_sdfs) {
+        if (!sc.has_medium) launch_wf_variant<PT_MATS_SDF, false>(sc, cam, S, wv, fa, fb, pass, stream);
+        else launch_wf_variant<PT_MATS_SDF, true>(sc, cam, S, wv, fa, fb, pass, stream);
+    } else if (!sc.has_medium) {
         if (am == LD) launch_wf_variant<LD, false>(sc, cam, S, wv, fa, fb, pass, stream);
         else launch_wf_variant<0u, false>(sc, cam, S, wv, fa, fb, pass, stream);
     } else {

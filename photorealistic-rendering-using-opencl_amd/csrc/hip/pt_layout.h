@@ -45,6 +45,7 @@ struct alignas(16) DevQuad {
     float normal[3]; float _p0;
     float anchor[3]; float _p1;
 };
+struct alignas(16) DevSdf { float pos[3]; uint32_t type; float params[4]; };     // Mesh.pos, Mesh.t, joker.s0123
 struct alignas(16) DevMaterial {
     float color[3]; float roughness;
     float eta[3]; uint32_t bits;      // t | lobes << 16 | dist << 24
@@ -60,10 +61,12 @@ struct DevScene {
     const TriNrm* tri_nrm;
     const DevSphere* spheres;
     const DevQuad* quads;
+    const DevSdf* sdfs;             // raymarched primitives (mesh indices n_spheres .. n_spheres + n_sdfs - 1)
     const DevMaterial* mats;        // [0] guard (zero), [1+i] mesh i, [1+n_meshes] OBJ material
     const float* env;               // RGB float
     int env_w, env_h;
-    uint32_t n_spheres, n_quads, quad_mesh_base, n_meshes;
+    uint32_t n_spheres, n_quads, quad_mesh_base, n_meshes, n_sdfs;
+    int marching_steps, shadow_marching_steps;
     uint32_t root_leaf_first, root_leaf_count;   // used when root_is_leaf
     int root_is_leaf;
     uint32_t light_sphere;          // LIGHT_INDICES[0] as index into spheres, or 0xFFFFFFFF

@@ -143,7 +143,7 @@ void host_scene::load_text(const std::string& text) {
             if (arr[i].HasMember("material") && arr[i]["material"].IsObject()) parse_material(&arr[i]["material"], m.mat);
         }
     }
-    // ---- sdfs (scene.h:307-364) -- carried through the ABI; the integrator rejects them (out of scope)
+    // ---- sdfs (scene.h:307-364): raymarched primitives, kernels/geometry/sdf.cl
     if (sc.HasMember("sdfs") && sc["sdfs"].IsArray()) {
         const json::Value& arr = sc["sdfs"];
         H_SDF = arr.Size() > 0;

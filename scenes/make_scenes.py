@@ -69,12 +69,21 @@ SCENES = {
                                             {"pos": [1.1, 0.5, 0.9], "radius": 0.5, "material": {"color": [0.6, 0.9, 0.7], "type": 3, "absorptive": 1}},    # DIEL, ABS_REFR
                                             {"pos": [0.2, 0.35, 1.4], "radius": 0.35,
                                              "material": {"color": [0.9, 0.7, 0.9], "type": 11, "dist": 0, "roughness": 0.15, "absorptive": 2}}]),          # ROUGH_DIEL Beckmann, ABS_REFR2
+    # SDF primitives ("next" row N4): raymarched sphere, box, round box and a tilted plane next to the teapot
+    "cornell_sdf": dict(cornell({"color": WHITE, "type": 1}), **{}),
     "cornell_quadlight": {"settings": settings(16, 6, 16, 16, 16),
                           "scene": {"obj": {"path": "teapot.obj", "material": {"color": WHITE, "type": 4, "dist": 2, "roughness": 0.2}},   # COAT over GGX
                                     "spheres": [{"pos": [1.0, 0.4, -0.8], "radius": 0.4, "material": {"color": [0.7, 0.7, 0.9], "type": 1}}],
                                     "quads": [quad([0.0, 3.95, 0.0], [-1.2, 0.0, 0.0], [0.0, 0.0, 1.2], [12.0, 12.0, 12.0])] + box_quads()}},
 }
 SCENES["cornell_quadlight"]["scene"]["quads"][0]["material"]["type"] = 0        # the quad is the (only) light
+SCENES["cornell_sdf"]["settings"] = dict(settings(12, 6, 12, 12, 12), MARCHING_STEPS=96, SHADOW_MARCHING_STEPS=48)
+SCENES["cornell_sdf"]["scene"]["sdfs"] = [
+    {"pos": [-1.2, 0.45, 0.9], "type": 4, "params": [0.45], "material": {"color": [0.9, 0.6, 0.3], "type": 1}},                    # SDF_SPHERE
+    {"pos": [1.25, 0.35, 0.7], "type": 5, "params": [0.35, 0.35, 0.35], "material": {"color": [0.3, 0.6, 0.9], "type": 4, "roughness": 0.2}},   # SDF_BOX, COAT
+    {"pos": [0.9, 0.3, -1.0], "type": 6, "params": [0.3, 0.2, 0.3, 0.08], "material": {"color": [0.8, 0.8, 0.8], "type": 10, "dist": 2, "roughness": 0.3}},  # SDF_ROUND_BOX
+    {"pos": [0.0, 0.0, -1.9], "type": 7, "params": [0.0, 0.2425356, 0.9701425, 0.0], "material": {"color": [0.6, 0.6, 0.6], "type": 1}},   # SDF_PLANE
+]
 
 if __name__ == "__main__":
     for name, doc in SCENES.items():

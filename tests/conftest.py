@@ -48,5 +48,6 @@ VARIANTS = {
     "cornell_media_rayleigh": ("cornell_media.json", 2, True),
     "cornell_mixed": ("cornell_mixed.json", 0, True),           # Phong rough conductor, mirror, absorbing (rough) dielectrics
     "cornell_quadlight": ("cornell_quadlight.json", 0, False),  # quad area light, coat over GGX, -alpha
+    "cornell_sdf": ("cornell_sdf.json", 0, True),               # raymarched SDF sphere / box / round box / plane
 }
 ALPHA_VARIANTS = {"cornell_quadlight"}                          # built / run with ALPHA_TESTING (the reference's -alpha flag)

@@ -200,6 +200,13 @@ def test_errors_are_reported_not_fatal(prt):
     with pytest.raises(prt.PrtError):
         prt.Renderer(cfg, device=4096)
     r.close()
+    # box primitives: geometry/box.cl is never included by the reference's kernel, they cannot render there either
+    import json
+    doc = json.load(open(os.path.join(prt.SCENES_DIR, "cornell_diffuse.json")))
+    doc["scene"]["boxes"] = [{"pos": [0, 0, 0], "scale": [1, 1, 1], "material": {"type": 1, "color": [1, 1, 1]}}]
+    boxed = prt.HostScene(json.dumps(doc), text=True)
+    with pytest.raises(prt.PrtError, match="box"):
+        prt.Renderer(boxed.config(), device=0)
 
 
 def test_dragon_standin_matches_oracle(prt, oracle):

@@ -1,0 +1,14 @@
+#!/bin/bash
+# A/B helper (development only): same bench arguments on several builds of libprt in one gpurun call
+#   tools/ab_scene.sh "<bench args>" base head ...
+P="photorealistic-rendering-using-opencl_amd"
+args=$1; shift
+for v in "$@"; do
+  if [ "$v" = "base" ]; then lib="$P/libprt.so"; else lib="$P/variants/libprt_$v.so"; fi
+  PRT_LIB=$PWD/$lib timeout -k 10 300 python3 bench.py --steps ${STEPS:-1} --warmup 1 --no-cpu-baseline $args 2>/dev/null | python3 -c "
+import sys,json
+for l in sys.stdin:
+    if l.startswith('{'):
+        j=json.loads(l); print('$v', 'Msamples/s', j['value'], 'Gseg/s', j['roofline']['gsegments_per_s'], 'avg_launch_ms', j['roofline']['avg_launch_ms'])
+"
+done

@@ -13,3 +13,4 @@ run roughdiel_env --scene cornell_roughdiel.json --env sky --spp ${SPP:-64}
 run media_iso --scene cornell_media.json --env sky --spp ${SPP:-64}
 run media_hg --scene cornell_media.json --env sky --phase hg --spp ${SPP:-64}
 run dragon_4k --scene cornell_dragon.json --width 3840 --height 2160 --spp ${SPPD:-16}
+run sdf_env --scene cornell_sdf.json --env sky --spp ${SPP:-64}
