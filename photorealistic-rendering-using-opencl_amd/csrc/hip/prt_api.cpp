@@ -215,6 +215,7 @@ extern "C" int prt_upload_scene(prt_ctx* c, const prt_scene_desc* s) {
     std::vector<NodePair> pairs;
     DevScene sc{};
     sc.root_is_leaf = 1;
+    sc.stack_levels = 1;
     if (T) {
         const prt_bvh_node* nodes = s->bvh_nodes;
         auto leaf_ok = [&](const prt_bvh_node& nd) { return (uint64_t)nd.first_child_or_primitive + nd.primitive_count <= T; };
@@ -278,6 +279,22 @@ extern "C" int prt_upload_scene(prt_ctx* c, const prt_scene_desc* s) {
                     }
                 }
             }
+            // Most entries a walk can hold: one push per pair with two inner children on the way down.
+            // The reference's stack has 64 entries (bvh.cl:131) and overflows silently beyond that.
+            uint32_t max_sp = 0;
+            std::vector<std::pair<uint32_t, uint32_t>> todo{{0u, 0u}};
+            while (!todo.empty()) {
+                const std::pair<uint32_t, uint32_t> it = todo.back();
+                todo.pop_back();
+                const NodePair& p = pairs[it.first];
+                const bool in0 = p.meta[1] == 0xFFFFFFFFu, in1 = p.meta[3] == 0xFFFFFFFFu;
+                const uint32_t sp = it.second + ((in0 && in1) ? 1u : 0u);
+                if (sp > max_sp) max_sp = sp;
+                if (in0) todo.push_back({p.meta[0], sp});
+                if (in1) todo.push_back({p.meta[2], sp});
+            }
+            if (max_sp + 1 > 64u) return fail(c, PRT_ERR_UNSUPPORTED, "prt_upload_scene: BVH needs more than the 64 traversal-stack entries of the reference (bvh.cl:131)");
+            sc.stack_levels = max_sp + 1;
         }
     } else {
         sc.root_leaf_first = 0; sc.root_leaf_count = 0;        // "no OBJ" = empty leaf root

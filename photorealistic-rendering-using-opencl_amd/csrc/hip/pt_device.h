@@ -200,25 +200,12 @@ PT_DEV bool hit_triangle(const TriGeom* __restrict__ tg, unsigned slot, const Ra
     return false;
 }
 
-#ifndef PT_STACK_DEPTH
-#define PT_STACK_DEPTH 64      // the reference's closest-hit stack size (bvh.cl:131)
-#endif
-// Traversal stack: a pop sits on the critical path of the walk (pop -> node index -> node fetch), so
-// the first levels live in LDS (~64-cycle round trip, [level][thread] layout = conflict-free)
-// instead of scratch memory; deeper levels spill to a scratch array.
+// Traversal stack in LDS, [level][thread] (conflict-free), `levels` chosen per scene from the tree
+// (prt_upload_scene: DevScene::stack_levels, never more than the reference's 64): a pop sits on the
+// critical path of the walk (pop -> node index -> node fetch), LDS is the closest memory there is.
 struct TravStack {
     unsigned* lds;         // this lane's column: level l is lds[l * stride]
     unsigned stride;       // threads per workgroup
-    unsigned* deep;        // scratch for levels >= lds_levels
-    int lds_levels;
-    PT_DEV void put(int sp, unsigned v) const {
-        if (sp < lds_levels) lds[(unsigned)sp * stride] = v;
-        else if (sp < PT_STACK_DEPTH) deep[sp - lds_levels] = v;
-    }
-    PT_DEV unsigned get(int sp) const {
-        if (sp < lds_levels) return lds[(unsigned)sp * stride];
-        return deep[(sp < PT_STACK_DEPTH ? sp : PT_STACK_DEPTH - 1) - lds_levels];
-    }
 };
 
 struct PairData { float4 b0, b1, b2; uint4 meta; };
@@ -250,42 +237,6 @@ PT_DEV PairTest test_pair(const PairData& d, const RayPre& p, float best_t) {
     return r;
 }
 
-// One step of bvh.cl:144-196 (closest hit) / :54-104 (any hit) at `node`, pair record already
-// loaded.  Same visiting order as the reference: both children's boxes are tested against the
-// CURRENT best_t before either leaf is tested; leaf children are tested immediately, left first;
-// of two inner children the nearer (by entry distance, ties -> left) is followed and the other
-// pushed.  Returns false when the walk is over (any-hit: `found` tells why).
-PT_DEV bool walk_step(const DevScene& sc, const bool ANY_HIT, const PairData& d, const RayPre& p, const Ray& ray,
-                      float& best_t, TriHit& th, bool& found, unsigned& node, int& sp, const TravStack& stack) {
-    const PairTest pt = test_pair(d, p, best_t);
-    const uint4 meta = d.meta;
-    bool go0 = pt.go0, go1 = pt.go1;
-    if (go0 && meta.y != 0xFFFFFFFFu) {                          // left child is a leaf
-        for (unsigned i = meta.x; i < meta.x + meta.y; ++i)
-            if (hit_triangle(sc.tri_geom, i, ray, best_t, th)) { found = true; if (ANY_HIT) return false; }
-        go0 = false;
-    }
-    if (go1 && meta.w != 0xFFFFFFFFu) {
-        for (unsigned i = meta.z; i < meta.z + meta.w; ++i)
-            if (hit_triangle(sc.tri_geom, i, ray, best_t, th)) { found = true; if (ANY_HIT) return false; }
-        go1 = false;
-    }
-    if (go0 != go1) {
-        node = go0 ? meta.x : meta.z;
-    } else if (go0) {
-        unsigned nearc = meta.x, farc = meta.z;
-        if (pt.entry0 > pt.entry1) { nearc = meta.z; farc = meta.x; }
-        stack.put(sp, farc);
-        ++sp;
-        node = nearc;
-    } else {
-        if (sp == 0) return false;
-        --sp;
-        node = stack.get(sp);
-    }
-    return true;
-}
-
 struct TravReq { bool want; f3 o, d; float tmax; };
 struct TravRes { bool found; float t; TriHit th; };
 
@@ -303,11 +254,43 @@ PT_DEV TravRes walk(const DevScene& sc, const bool ANY_HIT, const TravReq& rq, c
         return res;
     }
     const RayPre p = ray_pre(ray);
+    // One iteration = one step of bvh.cl:144-196 (closest hit) / :54-104 (any hit).  Same visiting
+    // order as the reference: both children's boxes are tested against the CURRENT best_t before
+    // either leaf is tested; leaf children are tested immediately, left first; of two inner children
+    // the nearer (by entry distance, ties -> left) is followed and the other pushed.  The kernel is
+    // bound by vector-ALU issue and most steps run for the one or two lanes of a wave that are still
+    // walking, so the shape below is the one with the fewest vector instructions per step: real
+    // branches (scalar mask work, free next to the vector pipe) rather than selects.
     unsigned node = 0;
-    int sp = 0;
+    unsigned sp = 0;
     for (;;) {
         const PairData d = load_pair(sc.pairs, node);
-        if (!walk_step(sc, ANY_HIT, d, p, ray, res.t, res.th, res.found, node, sp, stack)) break;
+        const PairTest pt = test_pair(d, p, res.t);
+        const uint4 meta = d.meta;
+        bool go0 = pt.go0, go1 = pt.go1;
+        if (go0 && meta.y != 0xFFFFFFFFu) {                      // left child is a leaf
+            for (unsigned i = meta.x; i < meta.x + meta.y; ++i)
+                if (hit_triangle(sc.tri_geom, i, ray, res.t, res.th)) { res.found = true; if (ANY_HIT) return res; }
+            go0 = false;
+        }
+        if (go1 && meta.w != 0xFFFFFFFFu) {
+            for (unsigned i = meta.z; i < meta.z + meta.w; ++i)
+                if (hit_triangle(sc.tri_geom, i, ray, res.t, res.th)) { res.found = true; if (ANY_HIT) return res; }
+            go1 = false;
+        }
+        if (go0 != go1) {
+            node = go0 ? meta.x : meta.z;
+        } else if (go0) {
+            unsigned nearc = meta.x, farc = meta.z;
+            if (pt.entry0 > pt.entry1) { nearc = meta.z; farc = meta.x; }
+            stack.lds[sp * stack.stride] = farc;
+            ++sp;
+            node = nearc;
+        } else {
+            if (sp == 0u) break;
+            --sp;
+            node = stack.lds[sp * stack.stride];
+        }
     }
     return res;
 }

@@ -5,8 +5,8 @@
 //   count_kernel                  sum of samples / segments / frozen pixels (Msamples/s accounting)
 //
 // Launch geometry: 256-thread workgroups = 4 waves; each wave owns an 8x8 pixel tile (primary rays of
-// one wave walk the same BVH nodes), a workgroup a 16x16 tile; 32 KiB of LDS per workgroup hold the
-// traversal stacks.  A 1920x1080 frame is 8 160 workgroups >> 256 CUs.
+// one wave walk the same BVH nodes), a workgroup a 16x16 tile; dynamic LDS (DevScene::stack_levels KiB per
+// workgroup) holds the traversal stacks.  A 1920x1080 frame is 8 160 workgroups >> 256 CUs.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -23,9 +23,6 @@ using namespace dev;
 #endif
 #ifndef PT_BLOCK
 #define PT_BLOCK 256        // threads per workgroup
-#endif
-#ifndef PT_LDS_STACK
-#define PT_LDS_STACK 32     // traversal-stack levels kept in LDS ([level][thread]: conflict-free, 32 KiB per workgroup)
 #endif
 
 template <unsigned MATS, bool MEDIUM>
@@ -58,10 +55,9 @@ __global__ __launch_bounds__(PT_BLOCK, PT_MIN_WAVES) void render_kernel(const De
         st.trans = e.z & 0xffffu; st.scatters = e.z >> 16;
         st.wasSpecular = (e.w & 1u) != 0; st.reset = (e.w & 2u) != 0;
     }
-    __shared__ unsigned lds_stack[PT_LDS_STACK * PT_BLOCK];
-    unsigned deep_stack[PT_STACK_DEPTH - PT_LDS_STACK];
+    extern __shared__ unsigned lds_stack[];                     // sc.stack_levels x PT_BLOCK, sized by the launch
     TravStack stk;
-    stk.lds = lds_stack + threadIdx.x; stk.stride = PT_BLOCK; stk.deep = deep_stack; stk.lds_levels = PT_LDS_STACK;
+    stk.lds = lds_stack + threadIdx.x; stk.stride = PT_BLOCK;
     bool ran = false;
     for (unsigned f = 0; f < fa.n_frames; ++f) {
         if (fa.spp_limit && st.reset && st.samples >= fa.spp_limit) break;     // frozen (the "N spp" rule)
@@ -333,10 +329,9 @@ __global__ __launch_bounds__(256, PT_SHADE_WAVES) void wf_shade_kernel(const Dev
 #define PT_TRAV_WAVES 8     // 64 VGPRs: the walk is a chain of dependent fetches, occupancy is what hides it
 #endif
 __global__ __launch_bounds__(256, PT_TRAV_WAVES) void wf_trav_kernel(const DevScene sc, const DevWave wv, const unsigned pass) {
-    __shared__ unsigned lds_stack[16 * 256];
-    unsigned deep_stack[PT_STACK_DEPTH - 16];
+    extern __shared__ unsigned lds_stack[];                     // sc.stack_levels x 256
     TravStack stk;
-    stk.lds = lds_stack + threadIdx.x; stk.stride = 256; stk.deep = deep_stack; stk.lds_levels = 16;
+    stk.lds = lds_stack + threadIdx.x; stk.stride = 256;
     const unsigned n = wv.qcount[pass & 1u];
     if (blockIdx.x == 0 && threadIdx.x == 0) wv.qcount[(pass + 1u) & 1u] = 0;       // next pass appends to the other counter
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
@@ -474,7 +469,7 @@ static void launch_variant(const DevScene& sc, const DevCamera& cam, const DevSt
                            hipStream_t stream) {
     constexpr unsigned TILE_W = PT_BLOCK / 16;
     const unsigned tiles_x = ((unsigned)fa.width + TILE_W - 1) / TILE_W, tiles_y = (unsigned)((fa.rows + 15) >> 4);
-    hipLaunchKernelGGL((render_kernel<MATS, MEDIUM>), dim3(tiles_x * tiles_y), dim3(PT_BLOCK), 0, stream, sc, cam, S, fa, fb);
+    hipLaunchKernelGGL((render_kernel<MATS, MEDIUM>), dim3(tiles_x * tiles_y), dim3(PT_BLOCK), sc.stack_levels * PT_BLOCK * sizeof(unsigned), stream, sc, cam, S, fa, fb);
 }
 
 // Variant choice = the AOT analogue of the reference's per-scene program build (include/CL/cl_kernel.h):
@@ -518,7 +513,7 @@ void launch_wf_pass(const DevScene& sc, const DevCamera& cam, const DevState& S,
         if (am == LD) launch_wf_variant<LD, true>(sc, cam, S, wv, fa, fb, pass, stream);
         else launch_wf_variant<0u, true>(sc, cam, S, wv, fa, fb, pass, stream);
     }
-    hipLaunchKernelGGL(wf_trav_kernel, dim3(trav_blocks), dim3(256), 0, stream, sc, wv, pass);
+    hipLaunchKernelGGL(wf_trav_kernel, dim3(trav_blocks), dim3(256), sc.stack_levels * 256 * sizeof(unsigned), stream, sc, wv, pass);
 }
 
 void launch_state_to_rtd(const DevState& S, prt_path_state* out, size_t n, hipStream_t stream) {

@@ -67,6 +67,7 @@ struct DevScene {
     int env_w, env_h;
     uint32_t n_spheres, n_quads, quad_mesh_base, n_meshes, n_sdfs;
     int marching_steps, shadow_marching_steps;
+    unsigned stack_levels;          // LDS traversal-stack levels per lane (most entries any walk can hold, + 1)
     uint32_t root_leaf_first, root_leaf_count;   // used when root_is_leaf
     int root_is_leaf;
     uint32_t light_sphere;          // LIGHT_INDICES[0] as index into spheres, or 0xFFFFFFFF
