@@ -293,7 +293,7 @@ extern "C" int prt_upload_scene(prt_ctx* c, const prt_scene_desc* s) {
                 if (in0) todo.push_back({p.meta[0], sp});
                 if (in1) todo.push_back({p.meta[2], sp});
             }
-            if (max_sp + 1 > 64u) return fail(c, PRT_ERR_UNSUPPORTED, "prt_upload_scene: BVH needs more than the 64 traversal-stack entries of the reference (bvh.cl:131)");
+            if (max_sp > 64u) return fail(c, PRT_ERR_UNSUPPORTED, "prt_upload_scene: BVH needs more than the 64 traversal-stack entries of the reference (bvh.cl:131)");
             sc.stack_levels = max_sp + 1;
         }
     } else {

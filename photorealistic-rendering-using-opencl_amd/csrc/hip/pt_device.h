@@ -53,6 +53,22 @@ PT_DEV float avg3(f3 v) { return (v.x * 1.0f + v.y * 1.0f + v.z * 1.0f) * 0.3333
 // min/max for the slab test only.  The operands there are compared with <=, > afterwards, so the
 // sign of a zero result is irrelevant, and a NaN operand (0 * inf) must be ignored exactly like
 // OpenCL fmin/fmax do -- which is what v_min_f32 / v_max_f32 implement in IEEE mode.
+// 1/x, correctly rounded (= prt_recip, the IEEE divide the CPU side does), in 6 vector instructions instead of the
+// 11 of the compiler's divide expansion: hardware estimate + one fma Newton step is exact whenever neither x nor
+// 1/x is subnormal (checked over all 2^32 inputs by prt_selftest_math fn 17, tests/test_gpu_parity.py); the rest
+// (zero, subnormal, huge, inf, nan) takes the divide.
+#ifndef PT_RECIP_STEPS
+#define PT_RECIP_STEPS 1
+#endif
+PT_DEV float hw_recip(float x) {
+    const unsigned e = (prt_f2u(x) >> 23) & 0xffu;
+    if (e - 2u < 251u) {                                        // 2^-125 <= |x| < 2^126
+        float r = __builtin_amdgcn_rcpf(x);
+        for (int k = 0; k < PT_RECIP_STEPS; ++k) r = __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+        return r;
+    }
+    return 1.0f / x;
+}
 PT_DEV float hw_min(float a, float b) { return __builtin_fminf(a, b); }
 PT_DEV float hw_max(float a, float b) { return __builtin_fmaxf(a, b); }
 
@@ -169,7 +185,7 @@ PT_DEV Ray create_cam_ray(int cx, int cy, int width, int height, const DevCamera
 struct RayPre { float ix, iy, iz, sx, sy, sz; bool nx, ny, nz; };
 PT_DEV RayPre ray_pre(const Ray& ray) {                          // bvh.cl:4-13 hoisted out of the node loop
     RayPre p;
-    p.ix = prt_recip(ray.dir.x); p.iy = prt_recip(ray.dir.y); p.iz = prt_recip(ray.dir.z);
+    p.ix = hw_recip(ray.dir.x); p.iy = hw_recip(ray.dir.y); p.iz = hw_recip(ray.dir.z);
     p.sx = -ray.origin.x * p.ix; p.sy = -ray.origin.y * p.iy; p.sz = -ray.origin.z * p.iz;
     p.nx = ray.dir.x < 0.0f; p.ny = ray.dir.y < 0.0f; p.nz = ray.dir.z < 0.0f;
     return p;
@@ -185,7 +201,7 @@ PT_DEV bool hit_triangle(const TriGeom* __restrict__ tg, unsigned slot, const Ra
     const f3 p0 = F3(a.x, a.y, a.z), e1 = F3(a.w, b.x, b.y), e2 = F3(b.z, b.w, c4.x), n = F3(c4.y, c4.z, c4.w);
     f3 c = p0 - ray.origin;
     f3 r = cross(ray.dir, c);
-    float inv_det = prt_recip(dot(n, ray.dir));
+    float inv_det = hw_recip(dot(n, ray.dir));
     float u = dot(r, e2) * inv_det;
     float v = dot(r, e1) * inv_det;
     float w = 1.0f - u - v;

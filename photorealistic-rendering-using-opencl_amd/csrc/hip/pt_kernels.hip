@@ -439,6 +439,16 @@ __global__ void tonemap_kernel(const float4* __restrict__ fb, uchar4* __restrict
 __global__ void selftest_math_kernel(int fn, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int n) {
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (i >= n) return;
+    if (fn == 17) {         // exhaustive: lane i compares hw_recip with the IEEE divide on the 65536 bit patterns (i << 16) + k
+        unsigned bad = 0;
+        for (unsigned k = 0; k < 65536u; ++k) {
+            const float v = prt_u2f(((unsigned)i << 16) + k);
+            const float q = 1.0f / v, h = hw_recip(v);
+            if (prt_f2u(q) != prt_f2u(h) && !(q != q && h != h)) ++bad;
+        }
+        out[i] = (float)bad;
+        return;
+    }
     const float x = a[i], y = b[i];
     float r;
     switch (fn) {
@@ -469,7 +479,10 @@ static void launch_variant(const DevScene& sc, const DevCamera& cam, const DevSt
                            hipStream_t stream) {
     constexpr unsigned TILE_W = PT_BLOCK / 16;
     const unsigned tiles_x = ((unsigned)fa.width + TILE_W - 1) / TILE_W, tiles_y = (unsigned)((fa.rows + 15) >> 4);
-    hipLaunchKernelGGL((render_kernel<MATS, MEDIUM>), dim3(tiles_x * tiles_y), dim3(PT_BLOCK), sc.stack_levels * PT_BLOCK * sizeof(unsigned), stream, sc, cam, S, fa, fb);
+    const size_t lds = (size_t)sc.stack_levels * PT_BLOCK * sizeof(unsigned);
+    if (lds > 65536u)        // only the 65-level case (a tree that fills the reference's 64-entry stack to the brim)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<MATS, MEDIUM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((render_kernel<MATS, MEDIUM>), dim3(tiles_x * tiles_y), dim3(PT_BLOCK), lds, stream, sc, cam, S, fa, fb);
 }
 
 // Variant choice = the AOT analogue of the reference's per-scene program build (include/CL/cl_kernel.h):
@@ -513,7 +526,9 @@ void launch_wf_pass(const DevScene& sc, const DevCamera& cam, const DevState& S,
         if (am == LD) launch_wf_variant<LD, true>(sc, cam, S, wv, fa, fb, pass, stream);
         else launch_wf_variant<0u, true>(sc, cam, S, wv, fa, fb, pass, stream);
     }
-    hipLaunchKernelGGL(wf_trav_kernel, dim3(trav_blocks), dim3(256), sc.stack_levels * 256 * sizeof(unsigned), stream, sc, wv, pass);
+    const size_t lds = (size_t)sc.stack_levels * 256 * sizeof(unsigned);
+    if (lds > 65536u) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wf_trav_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(wf_trav_kernel, dim3(trav_blocks), dim3(256), lds, stream, sc, wv, pass);
 }
 
 void launch_state_to_rtd(const DevState& S, prt_path_state* out, size_t n, hipStream_t stream) {

@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <map>
 #include <sstream>
 
 namespace prt {
@@ -41,6 +42,7 @@ bool ModelLoader::load_obj(const std::string& path) {
     std::ifstream f(path);
     std::vector<float3> pos, nor;
     Mesh mesh;
+    std::vector<size_t> needs_normals;          // faces whose corners came without a vn record
     std::string line;
     struct Corner { long v, n; };
     while (std::getline(f, line)) {
@@ -90,19 +92,42 @@ bool ModelLoader::load_obj(const std::string& path) {
                     return false;
                 }
                 if (cs[0].n == 0 || cs[k].n == 0 || cs[k + 1].n == 0) {
-                    // no vn: flat geometric normal (assimp's GenSmoothNormals is "next" row N2)
+                    // no vn: unit geometric normal for now, smoothed over the faces that share a position below
                     const float3 &a = face.points[0].pos, &b = face.points[1].pos, &c = face.points[2].pos;
                     float ux = b.x - a.x, uy = b.y - a.y, uz = b.z - a.z, vx = c.x - a.x, vy = c.y - a.y, vz = c.z - a.z;
                     float3 n{uy * vz - uz * vy, uz * vx - ux * vz, ux * vy - uy * vx};
                     float l = sqrtf(n.x * n.x + n.y * n.y + n.z * n.z);
                     if (l > 0.f) { n.x /= l; n.y /= l; n.z /= l; }
                     for (auto& p : face.points) p.nor = n;
+                    needs_normals.push_back(mesh.faces.size());
                 }
                 mesh.faces.push_back(face);
             }
         }
     }
     if (mesh.faces.empty()) { err_ = "no faces in '" + path + "'"; return false; }
+    // Files without vn records: the reference imports with aiProcessPreset_TargetRealtime_Quality
+    // (src/Models/model_loader.cpp:38), whose GenSmoothNormals step gives every vertex the normalised sum of the
+    // unit normals of the faces that meet at its position (smoothing-angle limit 175 degrees).  Same rule here, on
+    // bit-identical positions (assimp is an absent submodule, so this step has no oracle: SURVEY s8f row N2).
+    if (!needs_normals.empty()) {
+        struct Key { uint32_t x, y, z; bool operator<(const Key& o) const { return x != o.x ? x < o.x : (y != o.y ? y < o.y : z < o.z); } };
+        auto key = [](const float3& p) { Key k; float z0 = p.x + 0.0f, z1 = p.y + 0.0f, z2 = p.z + 0.0f;      // -0 -> +0
+                                         std::memcpy(&k.x, &z0, 4); std::memcpy(&k.y, &z1, 4); std::memcpy(&k.z, &z2, 4); return k; };
+        std::map<Key, std::vector<float3>> at;               // position -> unit normals of the faces around it
+        for (size_t fi : needs_normals)
+            for (auto& p : mesh.faces[fi].points) at[key(p.pos)].push_back(p.nor);
+        const float cos_limit = -0.99619470f;                // cos(175 deg)
+        for (size_t fi : needs_normals)
+            for (auto& p : mesh.faces[fi].points) {
+                const float3 own = p.nor;
+                float sx = 0.f, sy = 0.f, sz = 0.f;
+                for (const float3& n : at[key(p.pos)])
+                    if (n.x * own.x + n.y * own.y + n.z * own.z >= cos_limit) { sx += n.x; sy += n.y; sz += n.z; }
+                const float l = sqrtf(sx * sx + sy * sy + sz * sz);
+                if (l > 0.f) p.nor = {sx / l, sy / l, sz / l};
+            }
+    }
     scene_.meshes.push_back(std::move(mesh));
     return true;
 }

@@ -209,6 +209,75 @@ def test_errors_are_reported_not_fatal(prt):
         prt.Renderer(boxed.config(), device=0)
 
 
+def test_fast_reciprocal_is_the_ieee_divide_on_every_float(prt):
+    """hw_recip (estimate + one fma Newton step, divide for the extreme exponents) replaces the 1/x of the slab and
+    triangle tests; it must be the correctly rounded reciprocal for all 2^32 inputs"""
+    scene = prt.HostScene("cornell_diffuse.json")
+    r = prt.Renderer(scene.config(), device=0)
+    z = np.zeros(65536, dtype=np.float32)
+    bad = r.selftest_math(17, z, z)
+    r.close()
+    assert bad.sum() == 0, "hw_recip differs from 1.0f/x on %d inputs" % int(bad.sum())
+
+
+def _chain_bvh(levels):
+    """a hand-made BVH whose walk can stack `levels` entries: every chain node has two inner children, a
+    two-leaf stub and the rest of the chain (reference node layout, include/BVH/bvh.h:24-30)"""
+    node_t = np.dtype([("bounds", "<f4", 6), ("first", "<u4"), ("count", "<u4"), ("leaf", "u1"), ("_p", "u1", 3)])
+    n_nodes = 1 + 4 * levels + 2
+    nodes = np.zeros(n_nodes, dtype=node_t)
+    nodes["bounds"] = np.array([-1, 1, -1, 1, -1, 1], dtype=np.float32)
+    tri = 0
+    at, nxt = 0, 1
+    for _ in range(levels):
+        stub, chain = nxt, nxt + 1                      # children of the chain node sit side by side
+        nodes[at]["first"], nodes[at]["count"], nodes[at]["leaf"] = stub, 0, 0
+        l0 = nxt + 2
+        nodes[stub]["first"], nodes[stub]["leaf"] = l0, 0
+        for leaf in (l0, l0 + 1):
+            nodes[leaf]["first"], nodes[leaf]["count"], nodes[leaf]["leaf"] = tri, 1, 1
+            tri += 1
+        at, nxt = chain, nxt + 4
+    nodes[at]["first"], nodes[at]["leaf"] = nxt, 0       # the chain ends in one more two-leaf node
+    for leaf in (nxt, nxt + 1):
+        nodes[leaf]["first"], nodes[leaf]["count"], nodes[leaf]["leaf"] = tri, 1, 1
+        tri += 1
+    assert nxt + 2 == n_nodes
+    verts = np.zeros((tri * 3, 4), dtype=np.float32)
+    verts[1::3, 0] = 0.01
+    verts[2::3, 1] = 0.01
+    normals = np.zeros_like(verts)
+    normals[:, 2] = 1.0
+    return nodes, verts, normals, np.arange(tri, dtype=np.uint64)
+
+
+@pytest.mark.parametrize("levels,ok", [(64, True), (65, False)])
+def test_traversal_stack_limit_is_the_references(prt, levels, ok):
+    """the reference's closest-hit stack has 64 entries (bvh.cl:131) and overflows silently beyond; here a tree
+    that could stack more is refused at upload, one that fits renders"""
+    import ctypes as C
+    scene = prt.HostScene("cornell_diffuse.json")
+    nodes, verts, normals, idx = _chain_bvh(levels)
+    desc = prt.SceneDesc.from_buffer_copy(bytes(scene.desc))
+    desc.vertices = verts.ctypes.data_as(C.c_void_p)
+    desc.normals = normals.ctypes.data_as(C.c_void_p)
+    desc.primitive_indices = idx.ctypes.data_as(C.c_void_p)
+    desc.triangle_count = len(idx)
+    desc.bvh_nodes = nodes.ctypes.data_as(C.c_void_p)
+    desc.bvh_node_count = len(nodes)
+    r = prt.Renderer(scene.config(), device=0)
+    if ok:
+        r.upload_scene(desc)
+        r.set_camera(prt.default_camera(16, 8))
+        r.resize(16, 8)
+        r.render_frames(prt.seed_pairs(4))
+        assert np.isfinite(r.read_framebuffer()).all()
+    else:
+        with pytest.raises(prt.PrtError, match="64 traversal-stack entries"):
+            r.upload_scene(desc)
+    r.close()
+
+
 def test_dragon_standin_matches_oracle(prt, oracle):
     """871 k triangles, BVH depth 23: deep stacks (LDS + scratch levels), MALL-resident geometry"""
     prt.ensure_dragon_standin()

@@ -134,6 +134,28 @@ def test_obj_reader_and_soup_roundtrip(prt, tmp_path):
     assert lib.prth_convert_model(b"/nonexistent.obj", str(soup).encode(), err, 256) != 0
 
 
+def test_obj_without_normals_gets_smooth_normals(prt, tmp_path):
+    """assimp's GenSmoothNormals rule (the reference imports with aiProcessPreset_TargetRealtime_Quality): a vertex
+    gets the normalised sum of the unit normals of the faces meeting at its position; faces folded back by more
+    than 175 degrees do not smooth"""
+    obj = tmp_path / "tent.obj"
+    obj.write_text("v 0 0 0\nv 0 0 1\nv 1 -1 0\nv -1 -1 0\n"          # ridge (0,0,0)-(0,0,1), two slopes
+                   "f 1 2 3\nf 2 1 4\n"
+                   "v 5 0 0\nv 6 0 0\nv 5 1 0\nf 5 6 7\nf 5 7 6\n")        # a double-sided flap: opposite normals
+    lib = prt.load_library()
+    err = C.create_string_buffer(256)
+    soup = tmp_path / "tent.prtmesh"
+    assert lib.prth_convert_model(str(obj).encode(), str(soup).encode(), err, 256) == 0, err.value
+    tri = np.frombuffer(soup.read_bytes()[12:], dtype=np.float32).reshape(4, 3, 6)
+    n0 = np.cross(tri[0, 1, :3] - tri[0, 0, :3], tri[0, 2, :3] - tri[0, 0, :3]); n0 /= np.linalg.norm(n0)
+    n1 = np.cross(tri[1, 1, :3] - tri[1, 0, :3], tri[1, 2, :3] - tri[1, 0, :3]); n1 /= np.linalg.norm(n1)
+    ridge = (n0 + n1) / np.linalg.norm(n0 + n1)
+    assert np.allclose(tri[0, 0, 3:], ridge, atol=1e-6) and np.allclose(tri[0, 1, 3:], ridge, atol=1e-6)   # shared edge
+    assert np.allclose(tri[1, 0, 3:], ridge, atol=1e-6) and np.allclose(tri[1, 1, 3:], ridge, atol=1e-6)
+    assert np.allclose(tri[0, 2, 3:], n0, atol=1e-6) and np.allclose(tri[1, 2, 3:], n1, atol=1e-6)         # free corners
+    assert np.allclose(tri[2, :, 3:], [[0, 0, 1]] * 3) and np.allclose(tri[3, :, 3:], [[0, 0, -1]] * 3)    # no smoothing across 180 degrees
+
+
 @pytest.mark.skipif(not os.path.exists("/root/reference/resources/models/teapot.obj"), reason="reference not present")
 def test_committed_teapot_soup_is_the_reference_obj(prt, tmp_path):
     lib = prt.load_library()
