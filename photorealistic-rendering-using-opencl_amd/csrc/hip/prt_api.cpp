@@ -367,11 +367,7 @@ extern "C" int prt_upload_scene(prt_ctx* c, const prt_scene_desc* s) {
 extern "C" int prt_set_camera(prt_ctx* c, const prt_camera* cam) {
     CTX_CHECK(c);
     if (!cam) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_set_camera: null camera");
-    DevCamera d;
-    std::memcpy(d.position, cam->position, 16); std::memcpy(d.view, cam->view, 16); std::memcpy(d.up, cam->up, 16);
-    d.fov[0] = cam->fov[0]; d.fov[1] = cam->fov[1];
-    d.apertureRadius = cam->apertureRadius; d.focalDistance = cam->focalDistance;
-    c->cam = d;
+    make_dev_camera(*cam, c->cam);
     c->have_cam = true;
     return PRT_OK;
 }

@@ -31,21 +31,22 @@ namespace dev {
 #define PT_INV_FOUR_PI 0.0795774715459476678844418816863f
 
 #define PT_DEV __device__ __forceinline__
+#define PT_HD __host__ __device__ __forceinline__      // the few helpers the host shares (camera basis)
 
 struct f3 { float x, y, z; };
-PT_DEV f3 F3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
-PT_DEV f3 splat(float s) { return F3(s, s, s); }
-PT_DEV f3 operator+(f3 a, f3 b) { return F3(a.x + b.x, a.y + b.y, a.z + b.z); }
-PT_DEV f3 operator-(f3 a, f3 b) { return F3(a.x - b.x, a.y - b.y, a.z - b.z); }
-PT_DEV f3 operator*(f3 a, f3 b) { return F3(a.x * b.x, a.y * b.y, a.z * b.z); }
-PT_DEV f3 operator*(f3 a, float s) { return F3(a.x * s, a.y * s, a.z * s); }
-PT_DEV f3 operator/(f3 a, float s) { return F3(a.x / s, a.y / s, a.z / s); }
-PT_DEV f3 operator-(f3 a) { return F3(-a.x, -a.y, -a.z); }
-PT_DEV float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-PT_DEV f3 cross(f3 a, f3 b) { return F3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
-PT_DEV float length(f3 a) { return prt_sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
-PT_DEV f3 normalize(f3 a) { float inv = 1.0f / prt_sqrt(a.x * a.x + a.y * a.y + a.z * a.z); return F3(a.x * inv, a.y * inv, a.z * inv); }
-PT_DEV f3 ld3(const float* p) { return F3(p[0], p[1], p[2]); }
+PT_HD f3 F3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+PT_HD f3 splat(float s) { return F3(s, s, s); }
+PT_HD f3 operator+(f3 a, f3 b) { return F3(a.x + b.x, a.y + b.y, a.z + b.z); }
+PT_HD f3 operator-(f3 a, f3 b) { return F3(a.x - b.x, a.y - b.y, a.z - b.z); }
+PT_HD f3 operator*(f3 a, f3 b) { return F3(a.x * b.x, a.y * b.y, a.z * b.z); }
+PT_HD f3 operator*(f3 a, float s) { return F3(a.x * s, a.y * s, a.z * s); }
+PT_HD f3 operator/(f3 a, float s) { return F3(a.x / s, a.y / s, a.z / s); }
+PT_HD f3 operator-(f3 a) { return F3(-a.x, -a.y, -a.z); }
+PT_HD float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+PT_HD f3 cross(f3 a, f3 b) { return F3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+PT_HD float length(f3 a) { return prt_sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+PT_HD f3 normalize(f3 a) { float inv = 1.0f / prt_sqrt(a.x * a.x + a.y * a.y + a.z * a.z); return F3(a.x * inv, a.y * inv, a.z * inv); }
+PT_HD f3 ld3(const float* p) { return F3(p[0], p[1], p[2]); }
 PT_DEV f3 vexp(f3 a) { return F3(prt_exp(a.x), prt_exp(a.y), prt_exp(a.z)); }
 PT_DEV float fmax3(f3 v) { return prt_fmax(prt_fmax(v.x, v.y), v.z); }
 PT_DEV float avg3(f3 v) { return (v.x * 1.0f + v.y * 1.0f + v.z * 1.0f) * 0.3333333333333333333333333333333333333333333333f; }
@@ -143,15 +144,31 @@ PT_DEV bool check_refraction(f3 wi, f3 wo, float eta, float cosThetaT) {   // ut
 }
 
 // ---- camera, kernels/camera.cl:17-66 ---------------------------------------------------------
-PT_DEV Ray create_cam_ray(int cx, int cy, int width, int height, const DevCamera& cam, Rng& rng) {
-    f3 view = normalize(ld3(cam.view));
-    f3 up = normalize(ld3(cam.up));
+// The part of createCamRay (camera.cl:19-28) that is the same for every pixel: basis vectors and the two
+// tan() of the field of view.  Evaluated ONCE per prt_set_camera on the host -- same header, same IEEE
+// operations, so the bits are the ones every lane used to recompute at each path start (at ~15 % lane
+// occupancy, 10 lanes of a wave restart per frame).
+PT_HD void camera_basis(const prt_camera& in, DevCamera& cam) {
+    f3 view = normalize(ld3(in.view));
+    f3 up = normalize(ld3(in.up));
     f3 hAxis = normalize(cross(view, up));
     f3 vAxis = normalize(cross(hAxis, view));
-    f3 position = ld3(cam.position);
+    f3 position = ld3(in.position);
     f3 middle = position + view;
-    f3 horizontal = hAxis * prt_tan(cam.fov[0] * 0.5f * (PT_PI / 180));
-    f3 vertical = vAxis * prt_tan(cam.fov[1] * -0.5f * (PT_PI / 180));
+    f3 horizontal = hAxis * prt_tan(in.fov[0] * 0.5f * (PT_PI / 180));
+    f3 vertical = vAxis * prt_tan(in.fov[1] * -0.5f * (PT_PI / 180));
+    cam.position[0] = position.x; cam.position[1] = position.y; cam.position[2] = position.z;
+    cam.hAxis[0] = hAxis.x; cam.hAxis[1] = hAxis.y; cam.hAxis[2] = hAxis.z;
+    cam.vAxis[0] = vAxis.x; cam.vAxis[1] = vAxis.y; cam.vAxis[2] = vAxis.z;
+    cam.middle[0] = middle.x; cam.middle[1] = middle.y; cam.middle[2] = middle.z;
+    cam.horizontal[0] = horizontal.x; cam.horizontal[1] = horizontal.y; cam.horizontal[2] = horizontal.z;
+    cam.vertical[0] = vertical.x; cam.vertical[1] = vertical.y; cam.vertical[2] = vertical.z;
+    cam.apertureRadius = in.apertureRadius; cam.focalDistance = in.focalDistance;
+}
+
+PT_DEV Ray create_cam_ray(int cx, int cy, int width, int height, const DevCamera& cam, Rng& rng) {
+    const f3 hAxis = ld3(cam.hAxis), vAxis = ld3(cam.vAxis), position = ld3(cam.position);
+    const f3 middle = ld3(cam.middle), horizontal = ld3(cam.horizontal), vertical = ld3(cam.vertical);
     int pixelx = cx;
     int pixely = height - cy - 1;
     float sx = (float)pixelx / (width - 1.0f);

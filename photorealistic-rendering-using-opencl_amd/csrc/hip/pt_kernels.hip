@@ -531,6 +531,11 @@ void launch_wf_pass(const DevScene& sc, const DevCamera& cam, const DevState& S,
     hipLaunchKernelGGL(wf_trav_kernel, dim3(trav_blocks), dim3(256), lds, stream, sc, wv, pass);
 }
 
+void make_dev_camera(const prt_camera& in, DevCamera& out) {
+    out = DevCamera{};
+    camera_basis(in, out);
+}
+
 void launch_state_to_rtd(const DevState& S, prt_path_state* out, size_t n, hipStream_t stream) {
     hipLaunchKernelGGL(state_to_rtd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, S, out, n);
 }

@@ -14,6 +14,8 @@ const char* launch_render(const DevScene& sc, const DevCamera& cam, const DevSta
 // one wavefront pass: shade (resume / start, suspend at deep walks) + traverse the compacted queue
 void launch_wf_pass(const DevScene& sc, const DevCamera& cam, const DevState& S, const DevWave& wv, const FrameArgs& fa, float4* fb,
                     unsigned pass, unsigned trav_blocks, hipStream_t stream);
+// per-camera part of createCamRay (camera.cl:19-28), on the host with the arithmetic of pt_device.h
+void make_dev_camera(const prt_camera& in, DevCamera& out);
 void launch_state_to_rtd(const DevState& S, prt_path_state* out, size_t n, hipStream_t stream);
 void launch_rtd_to_state(const prt_path_state* in, const DevState& S, float4* fb, size_t n, hipStream_t stream);
 void launch_selftest_math(int fn, const float* a, const float* b, float* out, int n, hipStream_t stream);

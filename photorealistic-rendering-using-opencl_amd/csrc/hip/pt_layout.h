@@ -81,7 +81,15 @@ struct DevScene {
     uint32_t ntrans_mask;
 };
 
-struct DevCamera { float position[4], view[4], up[4]; float fov[2]; float apertureRadius, focalDistance; };
+// camera.cl:19-28 evaluated once per prt_set_camera (pt_device.h camera_basis), not per path start
+struct DevCamera {
+    float position[3], apertureRadius;
+    float hAxis[3], focalDistance;
+    float vAxis[3], pad0;
+    float middle[3], pad1;
+    float horizontal[3], pad2;
+    float vertical[3], pad3;
+};
 
 // path state planes
 struct DevState {
