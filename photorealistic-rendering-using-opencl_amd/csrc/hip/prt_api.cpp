@@ -3,6 +3,7 @@
 // call-by-call mapping).  No CPU fallback: every entry point needs a HIP device.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -207,6 +208,9 @@ extern "C" int prt_upload_scene(prt_ctx* c, const prt_scene_desc* s) {
             for (int k = 0; k < 3; ++k) d.anchor[k] = d.base[k] - (d.edge0[k] + d.edge1[k]) * 0.5f;
             d.e0e0 = d.edge0[0] * d.edge0[0] + d.edge0[1] * d.edge0[1] + d.edge0[2] * d.edge0[2];
             d.e1e1 = d.edge1[0] * d.edge1[0] + d.edge1[1] * d.edge1[1] + d.edge1[2] * d.edge1[2];
+            // pt_device.h out_of_unit_range: half an ulp of 1.0 scaled by the divisor, NaN = "divide instead"
+            auto half_ulp = [](float c) { return (c >= 9.094947017729282e-13f && c <= 1099511627776.0f) ? c * 5.9604644775390625e-08f : std::nanf(""); };
+            d.u0 = half_ulp(d.e0e0); d.u1 = half_ulp(d.e1e1);
         }
     }
     if (s->obj_material) mats[n_mesh + 1] = pack_material(*s->obj_material);

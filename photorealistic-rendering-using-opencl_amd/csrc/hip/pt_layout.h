@@ -42,8 +42,8 @@ struct alignas(16) DevQuad {
     float base[3]; float area;
     float edge0[3]; float e0e0;
     float edge1[3]; float e1e1;
-    float normal[3]; float _p0;
-    float anchor[3]; float _p1;
+    float normal[3]; float u0;     // u0 = e0e0 * 2^-24, u1 = e1e1 * 2^-24: half an ulp of 1.0 in units of the divisor, or a
+    float anchor[3]; float u1;     // NaN when the divisor is outside [2^-40, 2^40] (out_of_unit_range then divides)
 };
 struct alignas(16) DevSdf { float pos[3]; uint32_t type; float params[4]; };     // Mesh.pos, Mesh.t, joker.s0123
 struct alignas(16) DevMaterial {

@@ -220,6 +220,18 @@ def test_fast_reciprocal_is_the_ieee_divide_on_every_float(prt):
     assert bad.sum() == 0, "hw_recip differs from 1.0f/x on %d inputs" % int(bad.sum())
 
 
+@pytest.mark.parametrize("c", [1.0, 3.0, 0.7531, 16777215.0, 1.1920929e-07 * 3, 2.0 ** 40, 2.0 ** -40, 2.0 ** 41, 1e-20, 0.0, 5.960465e-08])
+def test_quad_edge_predicate_is_the_divide_on_every_float(prt, c):
+    """hit_quad compares x / c with 0 and 1 without dividing (pt_device.h out_of_unit_range); the predicate must equal
+    the reference expression for every binary32 x, for divisors in and out of the fast range"""
+    scene = prt.HostScene("cornell_diffuse.json")
+    r = prt.Renderer(scene.config(), device=0)
+    z = np.zeros(65536, dtype=np.float32)
+    bad = r.selftest_math(18, z, np.full(65536, c, dtype=np.float32))
+    r.close()
+    assert bad.sum() == 0, "c=%g: predicate differs from the divide on %d inputs" % (c, int(bad.sum()))
+
+
 def _chain_bvh(levels):
     """a hand-made BVH whose walk can stack `levels` entries: every chain node has two inner children, a
     two-leaf stub and the rest of the chain (reference node layout, include/BVH/bvh.h:24-30)"""
