@@ -11,8 +11,16 @@ every pixel has finished its S-th path (the reference's "N spp" in its own work 
 SURVEY.md s8d).  Inputs (scene, BVH, camera, seed table) are resident in HBM before the timed
 region.  With N > 1 the frame is split into interleaved row blocks, one set per rank (pixels are
 independent; seeds use global pixel coordinates, so the union is bit-identical to the 1-GPU
-image), and ONE RCCL reduce(sum) of the zero-padded full-size framebuffer per step merges them on
-rank 0 -- inside the timed region.  Total work is fixed as N grows: "scaling": "strong".
+image of that frame), and ONE RCCL reduce(sum) of the zero-padded full-size framebuffer per step
+merges them on rank 0 -- inside the timed region.
+
+Scaling.  Default "weak": per-GPU work is fixed -- the N-GPU frame has N x the pixels of the base
+frame (same scene, camera and aspect, both dimensions x sqrt(N): 1920x1080, 2720x1530, 3840x2160,
+5424x3051), so every rank renders ~2.07 M pixels x spp as the 1-GPU run does.  `--scaling strong`
+keeps the base frame and splits it N ways instead; at 1080p that stops scaling early for a
+structural reason measured in DESIGN.md s5: the frame has 32 400 waves of pixels, eight MI355X hold
+32 768 resident waves, so the run time falls to the sequential chain of the slowest tile
+(spp x path length segments, one after the other), not to work / N.
 
 The JSON line also carries
   roofline      the dominant kernel (render_kernel) priced in ALGORITHMIC bytes: 240 B per pixel
@@ -50,6 +58,8 @@ def main():
     ap.add_argument("--scene", default="cornell_diffuse.json")
     ap.add_argument("--env", default="", choices=["", "sky"], help="sky = the procedural 1024x512 HDR stand-in (configs 3, 4)")
     ap.add_argument("--phase", default="isotropic", choices=["isotropic", "hg", "rayleigh"], help="phase function of the global medium (config 4)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = N x the pixels (frame x sqrt(N) per dimension), strong = the base frame split N ways")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -86,6 +96,9 @@ def main():
         ge.build()
 
     W, H, spp = a.width, a.height, a.spp
+    if world > 1 and a.scaling == "weak":
+        W = int(round(a.width * world ** 0.5 / 16.0)) * 16
+        H = int(round(a.height * W / float(a.width)))
     if "dragon" in a.scene:
         prt.ensure_dragon_standin()
     scene = prt.HostScene(a.scene)
@@ -167,18 +180,18 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("workload") == "%dx%d_%dspp_%s" % (W, H, spp, a.scene):
+                if tj.get("workload") == "%dx%d_%dspp_%s" % (a.width, a.height, spp, a.scene):   # per launch of the base frame = per rank
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
-            "metric": "Msamples/s (width x height x spp / s) at %dx%d" % (W, H),
+            "metric": "Msamples/s (width x height x spp / s) at %dx%d" % (a.width, a.height),
             "value": round(msamples, 3),
             "unit": "Msamples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": a.scaling if world > 1 else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -188,7 +201,8 @@ def main():
                        "scene": a.scene, "width": W, "height": H, "spp": spp,
                        "mean_path_length": round(total_segments / max(total_samples, 1.0), 4),
                        "segments_per_step": total_segments,
-                       "parallelism": "single GPU" if world == 1 else "interleaved 16-row blocks over %d ranks + 1 RCCL reduce" % world},
+                       "base_frame": "%dx%d" % (a.width, a.height),
+                       "parallelism": "single GPU" if world == 1 else "%s scaling: %dx%d frame in interleaved 16-row blocks over %d ranks + 1 RCCL reduce" % (a.scaling, W, H, world)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                          "kernel": "render_kernel", "algorithmic_bytes_per_segment": ALGO_BYTES_PER_SEGMENT,
