@@ -26,9 +26,11 @@ The JSON line also carries
   roofline      the dominant kernel (render_kernel) priced in ALGORITHMIC bytes: 240 B per pixel
                 segment (112 B state read + 112 B state write + 16 B image write, what the
                 reference moves per work-item per launch) x segments executed, divided by the
-                kernel time measured live with HIP events on the launch stream (libprt does it
-                around its launches).  peak = 8 TB/s HBM3E.  `traffic` = measured HBM bytes per
-                launch from the rocprofv3 PMC passes committed under profiles/ (null if absent).
+                kernel time measured live with HIP events (libprt does it: `kernel_wall_ms` around
+                all the launches of a step on the caller's stream, `avg_launch_ms` around each
+                launch on the internal stream it ran on -- two launches, covering interleaved sets
+                of tiles, are in flight at a time).  peak = 8 TB/s HBM3E.  `traffic` = measured HBM
+                bytes per launch from the rocprofv3 PMC passes under profiles/ (null if absent).
   cpu_baseline  oracle/pt_oracle.c (a scalar-per-pixel CPU port, multi-threaded over pixels) on a
                 bounded sample of the same workload, rank 0, N = 1 only.
 """
@@ -123,11 +125,13 @@ def main():
         r.set_row_blocks(W, H, par.BLOCK_ROWS, world, rank)
         tile = torch.zeros((len(my_rows), W, 4), dtype=torch.float32, device="cuda")
 
-    kernel_ms = 0.0
+    kernel_ms = 0.0          # wall time of the GPU work of the timed steps (HIP events around all of it)
+    kernel_sum_ms = 0.0      # sum of the durations of the individual launches (HIP events around each)
     launches = 0
+    concurrent = 1
 
     def step(timed):
-        nonlocal kernel_ms, launches
+        nonlocal kernel_ms, kernel_sum_ms, launches, concurrent
         r.reset()
         r.render_spp(spp, seeds)
         if world > 1:
@@ -136,7 +140,9 @@ def main():
         if timed:
             st = r.stats()
             kernel_ms += st.kernel_ms
+            kernel_sum_ms += st.kernel_sum_ms
             launches += st.launches
+            concurrent = st.concurrent
 
     def sync():
         if world > 1:
@@ -206,7 +212,12 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                          "kernel": "render_kernel", "algorithmic_bytes_per_segment": ALGO_BYTES_PER_SEGMENT,
-                         "launches": launches, "avg_launch_ms": round(kernel_ms / max(launches, 1), 4),
+                         "launches": launches, "avg_launch_ms": round(kernel_sum_ms / max(launches, 1), 4),
+                         "concurrent_launches": concurrent, "kernel_wall_ms": round(kernel_ms, 3),
+                         "note": "libprt keeps %d launches of render_kernel in flight (interleaved sets of tiles on internal streams): "
+                                 "`achieved` = algorithmic bytes of all launches / wall time of the GPU work (HIP events around it); "
+                                 "`avg_launch_ms` = mean duration of one launch (HIP events around each, = the profiler's average), "
+                                 "launches x avg_launch_ms ~ %d x kernel_wall_ms" % (concurrent, concurrent),
                          "gsegments_per_s": round(own_segments * steps / (kernel_ms * 1e-3) / 1e9, 4) if kernel_ms > 0 else 0.0},
         }
         if world == 1 and not a.no_cpu_baseline:

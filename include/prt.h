@@ -85,12 +85,20 @@ typedef struct prt_scene_desc {
 } prt_scene_desc;
 
 typedef struct prt_stats {
-    double kernel_ms;        /* device time of the render kernels of the last prt_render_* call (HIP events on the context's stream) */
+    double kernel_ms;        /* device time of the render kernels of the last prt_render_* call (HIP events on the context's
+                                stream, around everything the call queued: wall time of the GPU work) */
     uint32_t launches;       /* kernel launches in that call */
     uint32_t frames;         /* frames (= segments per live pixel) executed in that call */
     uint64_t samples;        /* sum over pixels of RLH.samples (paths started)   -- filled by prt_query_counts */
     uint64_t segments;       /* sum over pixels of acc.w (segments executed)     -- filled by prt_query_counts */
     uint64_t finished_pixels;/* pixels frozen by the spp rule                     -- filled by prt_query_counts */
+    double kernel_sum_ms;    /* sum of the durations of the individual launches (HIP events around each launch on the
+                                stream it ran on; prt_render_spp only, else = kernel_ms).  The megakernel keeps
+                                `concurrent` launches in flight (interleaved sets of tiles on internal streams), so
+                                kernel_sum_ms ~ concurrent x kernel_ms; kernel_sum_ms / launches is what a profiler
+                                reports as the kernel's average duration */
+    uint32_t concurrent;     /* launches in flight at a time (internal streams; PRT_STREAMS, default 2) */
+    uint32_t _pad;
 } prt_stats;
 
 typedef struct prt_ctx prt_ctx;

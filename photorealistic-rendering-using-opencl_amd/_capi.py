@@ -56,7 +56,8 @@ class SceneDesc(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("launches", C.c_uint32), ("frames", C.c_uint32),
-                ("samples", C.c_uint64), ("segments", C.c_uint64), ("finished_pixels", C.c_uint64)]
+                ("samples", C.c_uint64), ("segments", C.c_uint64), ("finished_pixels", C.c_uint64),
+                ("kernel_sum_ms", C.c_double), ("concurrent", C.c_uint32), ("_pad", C.c_uint32)]
 
 
 assert C.sizeof(Material) == 64 and C.sizeof(Mesh) == 256 and C.sizeof(BvhNode) == 36 and C.sizeof(Camera) == 80

@@ -7,7 +7,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "prt.h"
@@ -39,7 +41,16 @@ struct prt_ctx {
     DevState S{};
     float4* fb = nullptr;
     int32_t* d_seeds = nullptr; size_t seeds_cap = 0;
-    unsigned long long* d_counters = nullptr;     // [0] unfinished, [1..3] count_kernel
+    unsigned long long* d_counters = nullptr;     // [0] unfinished, [1..3] count_kernel, [4 + j] unfinished of sub-part j
+    // The megakernel renders the frame as n_sub interleaved sets of tiles, each on its own stream: the sets are
+    // independent (pixels are), so while one set's launch drains on its slowest tiles the other fills the CUs.
+    static constexpr int MAX_SUB = 4;
+    int n_sub = 2;
+    hipStream_t sub_stream[MAX_SUB] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t sub_ev[MAX_SUB] = {nullptr, nullptr, nullptr, nullptr};       // end of a sub-part's launch
+    hipEvent_t sub_ev0[MAX_SUB] = {nullptr, nullptr, nullptr, nullptr};      // its start (prt_render_spp times every launch)
+    hipEvent_t fork_ev = nullptr;
+    unsigned long long* h_unfinished = nullptr;   // pinned, MAX_SUB entries
     // wavefront pipeline (optional)
     int pipeline = 0;                              // 0 = megakernel, 1 = wavefront
     DevWave wv{};
@@ -81,11 +92,21 @@ extern "C" int prt_create(int device, const prt_config* cfg, prt_ctx** out) {
     c->cfg = *cfg;
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
-        (e = hipMalloc(reinterpret_cast<void**>(&c->d_counters), 4 * sizeof(unsigned long long))) != hipSuccess) {
+        (e = hipMalloc(reinterpret_cast<void**>(&c->d_counters), (4 + prt_ctx::MAX_SUB) * sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipHostMalloc(reinterpret_cast<void**>(&c->h_unfinished), prt_ctx::MAX_SUB * sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming)) != hipSuccess) {
         g_global_error = std::string("prt_create: ") + hipGetErrorString(e);
-        delete c;
+        prt_destroy(c);
         return PRT_ERR_HIP;
     }
+    if (const char* ev = std::getenv("PRT_STREAMS")) { const int k = std::atoi(ev); if (k >= 1 && k <= prt_ctx::MAX_SUB) c->n_sub = k; }
+    for (int j = 0; j < c->n_sub && c->n_sub > 1; ++j)
+        if ((e = hipStreamCreateWithFlags(&c->sub_stream[j], hipStreamNonBlocking)) != hipSuccess ||
+            (e = hipEventCreate(&c->sub_ev[j])) != hipSuccess || (e = hipEventCreate(&c->sub_ev0[j])) != hipSuccess) {
+            g_global_error = std::string("prt_create: ") + hipGetErrorString(e);
+            prt_destroy(c);
+            return PRT_ERR_HIP;
+        }
     c->stream = c->own_stream;
     if (const char* e = std::getenv("PRT_PIPELINE")) c->pipeline = (std::strcmp(e, "wavefront") == 0 || std::strcmp(e, "1") == 0) ? 1 : 0;
     *out = c;
@@ -135,7 +156,14 @@ static void free_scene(prt_ctx* c) {
 extern "C" void prt_destroy(prt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (int j = 0; j < prt_ctx::MAX_SUB; ++j) {
+        if (c->sub_stream[j]) { (void)hipStreamSynchronize(c->sub_stream[j]); (void)hipStreamDestroy(c->sub_stream[j]); }
+        if (c->sub_ev[j]) (void)hipEventDestroy(c->sub_ev[j]);
+        if (c->sub_ev0[j]) (void)hipEventDestroy(c->sub_ev0[j]);
+    }
+    if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
+    if (c->h_unfinished) (void)hipHostFree(c->h_unfinished);
     free_frame(c);
     free_wave(c);
     free_scene(c);
@@ -478,7 +506,25 @@ static FrameArgs frame_args(prt_ctx* c, uint32_t first_frame, uint32_t n, const 
     fa.block_rows = c->block_rows; fa.n_parts = c->n_parts; fa.part = c->part;
     fa.first_frame = first_frame; fa.n_frames = n; fa.seed_pairs = d_seeds; fa.spp_limit = spp;
     fa.unfinished = count ? c->d_counters : nullptr;
+    fa.tile_first = 0; fa.tile_stride = 1;
     return fa;
+}
+
+// sub-parts the megakernel renders this frame part in (1 = one launch covers every tile)
+static int sub_parts(const prt_ctx* c) { return (c->n_sub > 1 && c->sub_stream[0]) ? c->n_sub : 1; }
+// the internal streams start behind everything already queued on the caller's stream ...
+static int fork_streams(prt_ctx* c, int K) {
+    HIPCHK(c, hipEventRecord(c->fork_ev, c->stream));
+    for (int j = 0; j < K; ++j) HIPCHK(c, hipStreamWaitEvent(c->sub_stream[j], c->fork_ev, 0));
+    return PRT_OK;
+}
+// ... and the caller's stream continues behind them
+static int join_streams(prt_ctx* c, int K) {
+    for (int j = 0; j < K; ++j) {
+        HIPCHK(c, hipEventRecord(c->sub_ev[j], c->sub_stream[j]));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->sub_ev[j], 0));
+    }
+    return PRT_OK;
 }
 
 // Wavefront pipeline: passes of (shade, traverse) until every pixel has done its n_frames segments (or froze).
@@ -521,7 +567,7 @@ extern "C" int prt_render_frames(prt_ctx* c, uint32_t first_frame, uint32_t n_fr
     if (rc) return rc;
     if (first_frame == 0 || (n_frames && !seed_pairs)) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_render_frames: frames start at 1 and need seed pairs");
     HIPCHK(c, hipSetDevice(c->device));
-    c->stats.launches = 0; c->stats.frames = 0; c->stats.kernel_ms = 0.0;
+    c->stats.launches = 0; c->stats.frames = 0; c->stats.kernel_ms = 0.0; c->stats.kernel_sum_ms = 0.0; c->stats.concurrent = 1;
     if (!n_frames) return PRT_OK;
     if ((rc = ensure_seeds(c, seed_pairs, n_frames))) return rc;
     if (c->pipeline == 1) {
@@ -530,13 +576,21 @@ extern "C" int prt_render_frames(prt_ctx* c, uint32_t first_frame, uint32_t n_fr
         return rc;
     }
     const unsigned step = frames_per_launch();
+    const int K = sub_parts(c);
+    c->stats.concurrent = (uint32_t)K;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    if (K > 1 && (rc = fork_streams(c, K))) return rc;
     for (uint32_t f = 0; f < n_frames; f += step) {
         const uint32_t n = (n_frames - f < step) ? n_frames - f : step;
-        c->variant = launch_render(c->sc, c->cam, c->S, frame_args(c, first_frame + f, n, c->d_seeds + 2 * (size_t)f, 0, false), c->fb, c->stream);
-        ++c->stats.launches;
+        for (int j = 0; j < K; ++j) {
+            FrameArgs fa = frame_args(c, first_frame + f, n, c->d_seeds + 2 * (size_t)f, 0, false);
+            fa.tile_first = (uint32_t)j; fa.tile_stride = (uint32_t)K;
+            c->variant = launch_render(c->sc, c->cam, c->S, fa, c->fb, K > 1 ? c->sub_stream[j] : c->stream);
+            ++c->stats.launches;
+        }
     }
     HIPCHK(c, hipGetLastError());
+    if (K > 1 && (rc = join_streams(c, K))) return rc;
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     c->timing_pending = true;
     c->stats.frames = n_frames;
@@ -549,7 +603,7 @@ extern "C" int prt_render_spp(prt_ctx* c, uint32_t spp, uint32_t max_frames, con
     if (rc) return rc;
     if (!spp || !max_frames || !seed_pairs) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_render_spp: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
-    c->stats.launches = 0; c->stats.frames = 0; c->stats.kernel_ms = 0.0;
+    c->stats.launches = 0; c->stats.frames = 0; c->stats.kernel_ms = 0.0; c->stats.kernel_sum_ms = 0.0; c->stats.concurrent = 1;
     if ((rc = ensure_seeds(c, seed_pairs, max_frames))) return rc;
     if (c->pipeline == 1) {
         rc = render_wavefront(c, 1, max_frames, spp, frames_used);
@@ -557,16 +611,61 @@ extern "C" int prt_render_spp(prt_ctx* c, uint32_t spp, uint32_t max_frames, con
         return rc;
     }
     const unsigned step = frames_per_launch();
+    const int K = sub_parts(c);
+    c->stats.concurrent = (uint32_t)K;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     uint32_t f = 0;
     unsigned long long unfinished = 1;
-    while (f < max_frames && unfinished) {
-        const uint32_t n = (max_frames - f < step) ? max_frames - f : step;
-        HIPCHK(c, hipMemsetAsync(c->d_counters, 0, sizeof(unsigned long long), c->stream));
-        c->variant = launch_render(c->sc, c->cam, c->S, frame_args(c, 1 + f, n, c->d_seeds + 2 * (size_t)f, spp, true), c->fb, c->stream);
-        ++c->stats.launches;
-        f += n;
-        HIPCHK(c, hipMemcpyAsync(&unfinished, c->d_counters, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    if (K == 1) {
+        while (f < max_frames && unfinished) {
+            const uint32_t n = (max_frames - f < step) ? max_frames - f : step;
+            HIPCHK(c, hipMemsetAsync(c->d_counters, 0, sizeof(unsigned long long), c->stream));
+            c->variant = launch_render(c->sc, c->cam, c->S, frame_args(c, 1 + f, n, c->d_seeds + 2 * (size_t)f, spp, true), c->fb, c->stream);
+            ++c->stats.launches;
+            f += n;
+            HIPCHK(c, hipMemcpyAsync(&unfinished, c->d_counters, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+    } else {
+        // every sub-part advances on its own stream until its own pixels are frozen; the host only feeds the next
+        // launch of a sub-part when the previous one has reported how many of its pixels are still running
+        if ((rc = fork_streams(c, K))) return rc;
+        uint32_t fj[prt_ctx::MAX_SUB] = {0, 0, 0, 0};
+        bool in_flight[prt_ctx::MAX_SUB] = {false, false, false, false}, done[prt_ctx::MAX_SUB] = {false, false, false, false};
+        int n_done = 0;
+        bool exhausted = false;
+        while (n_done < K) {
+            bool progressed = false;
+            for (int j = 0; j < K; ++j) {
+                if (done[j]) continue;
+                if (in_flight[j]) {
+                    const hipError_t q = hipEventQuery(c->sub_ev[j]);
+                    if (q == hipErrorNotReady) continue;
+                    HIPCHK(c, q);
+                    in_flight[j] = false; progressed = true;
+                    float ms = 0.f;
+                    if (hipEventElapsedTime(&ms, c->sub_ev0[j], c->sub_ev[j]) == hipSuccess) c->stats.kernel_sum_ms += ms;
+                    if (c->h_unfinished[j] == 0) { done[j] = true; ++n_done; continue; }
+                    if (fj[j] >= max_frames) { done[j] = true; ++n_done; exhausted = true; continue; }
+                }
+                const uint32_t n = (max_frames - fj[j] < step) ? max_frames - fj[j] : step;
+                FrameArgs fa = frame_args(c, 1 + fj[j], n, c->d_seeds + 2 * (size_t)fj[j], spp, true);
+                fa.unfinished = c->d_counters + 4 + j;
+                fa.tile_first = (uint32_t)j; fa.tile_stride = (uint32_t)K;
+                HIPCHK(c, hipMemsetAsync(fa.unfinished, 0, sizeof(unsigned long long), c->sub_stream[j]));
+                HIPCHK(c, hipEventRecord(c->sub_ev0[j], c->sub_stream[j]));
+                c->variant = launch_render(c->sc, c->cam, c->S, fa, c->fb, c->sub_stream[j]);
+                HIPCHK(c, hipMemcpyAsync(&c->h_unfinished[j], fa.unfinished, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->sub_stream[j]));
+                HIPCHK(c, hipEventRecord(c->sub_ev[j], c->sub_stream[j]));
+                ++c->stats.launches;
+                fj[j] += n;
+                in_flight[j] = true; progressed = true;
+            }
+            if (!progressed) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+        for (int j = 0; j < K; ++j) f = fj[j] > f ? fj[j] : f;
+        unfinished = exhausted ? 1 : 0;
+        if ((rc = join_streams(c, K))) return rc;
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     HIPCHK(c, hipGetLastError());
@@ -592,6 +691,7 @@ extern "C" int prt_synchronize(prt_ctx* c) {
     if (c->timing_pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->stats.kernel_ms = ms;
+        if (c->stats.kernel_sum_ms == 0.0) c->stats.kernel_sum_ms = c->stats.kernel_ms;      // launches were not timed one by one
         c->timing_pending = false;
     }
     return PRT_OK;

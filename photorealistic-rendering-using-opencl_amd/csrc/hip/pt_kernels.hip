@@ -31,7 +31,8 @@ __global__ __launch_bounds__(PT_BLOCK, PT_MIN_WAVES) void render_kernel(const De
     // workgroup tile: (PT_BLOCK / 128) x 2 waves of 8x8 pixels
     constexpr int TILE_W = PT_BLOCK / 16, WAVES_X = TILE_W / 8;
     const int tiles_x = (fa.width + TILE_W - 1) / TILE_W;
-    const int tile_x = (int)(blockIdx.x % (unsigned)tiles_x), tile_y = (int)(blockIdx.x / (unsigned)tiles_x);
+    const unsigned tile = blockIdx.x * fa.tile_stride + fa.tile_first;
+    const int tile_x = (int)(tile % (unsigned)tiles_x), tile_y = (int)(tile / (unsigned)tiles_x);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int lx = tile_x * TILE_W + (wave % WAVES_X) * 8 + (lane & 7);
     const int ly = tile_y * 16 + (wave / WAVES_X) * 8 + (lane >> 3);
@@ -494,7 +495,10 @@ static void launch_variant(const DevScene& sc, const DevCamera& cam, const DevSt
     const size_t lds = (size_t)sc.stack_levels * PT_BLOCK * sizeof(unsigned);
     if (lds > 65536u)        // only the 65-level case (a tree that fills the reference's 64-entry stack to the brim)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<MATS, MEDIUM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((render_kernel<MATS, MEDIUM>), dim3(tiles_x * tiles_y), dim3(PT_BLOCK), lds, stream, sc, cam, S, fa, fb);
+    const unsigned n_tiles = tiles_x * tiles_y;
+    if (fa.tile_first >= n_tiles) return;
+    const unsigned grid = (n_tiles - fa.tile_first + fa.tile_stride - 1) / fa.tile_stride;      // tiles of this sub-part
+    hipLaunchKernelGGL((render_kernel<MATS, MEDIUM>), dim3(grid), dim3(PT_BLOCK), lds, stream, sc, cam, S, fa, fb);
 }
 
 // Variant choice = the AOT analogue of the reference's per-scene program build (include/CL/cl_kernel.h):

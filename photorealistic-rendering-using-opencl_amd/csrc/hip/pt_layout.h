@@ -125,6 +125,7 @@ struct FrameArgs {
     const int32_t* seed_pairs;              // device, 2 * n_frames
     uint32_t spp_limit;
     unsigned long long* unfinished;         // device counter: pixels not yet frozen (spp mode), or null
+    uint32_t tile_first, tile_stride;       // this launch covers the tiles tile_first + k * tile_stride (sub-part of the frame)
 };
 
 }  // namespace prt

@@ -209,6 +209,30 @@ def test_errors_are_reported_not_fatal(prt):
         prt.Renderer(boxed.config(), device=0)
 
 
+@pytest.mark.parametrize("streams", ["1", "2", "3", "4"])
+def test_internal_streams_are_invisible(prt, oracle, streams, monkeypatch):
+    """the megakernel renders interleaved sets of tiles on PRT_STREAMS internal streams (default 2); any number gives
+    the bits of the reference golden, in frame mode and in spp mode, on the context's own and on a caller's stream"""
+    monkeypatch.setenv("PRT_STREAMS", streams)
+    variant = "cornell_diffuse"
+    g = np.load(os.path.join(GOLDEN, variant + ".npz"))
+    W, H, frames = int(g["width"]), int(g["height"]), int(g["frames"])
+    scene, cfg, cam, env, r = _setup(prt, variant, W, H)
+    r.render_frames(prt.seed_pairs(frames))
+    gstate = np.ascontiguousarray(g["state"]).view(oracle.PATH_STATE_DTYPE).reshape(-1)
+    _assert_same(oracle, gstate, g["image"], r.read_state(), r.read_framebuffer(), "streams=%s vs golden" % streams)
+    assert r.stats().concurrent == int(streams)
+    gs = np.load(os.path.join(GOLDEN, "cornell_diffuse_spp.npz"))
+    r.reset()
+    used = r.render_spp(int(gs["spp"]), prt.seed_pairs(int(gs["frames"])))
+    sstate = np.ascontiguousarray(gs["state"]).view(oracle.PATH_STATE_DTYPE).reshape(-1)
+    _assert_same(oracle, sstate, gs["image"], r.read_state(), r.read_framebuffer(), "streams=%s spp vs golden" % streams)
+    assert 0 < used <= int(gs["frames"])
+    st = r.stats()
+    assert st.kernel_ms > 0 and st.kernel_sum_ms >= 0.5 * st.kernel_ms and st.launches >= int(streams)
+    r.close()
+
+
 def test_fast_reciprocal_is_the_ieee_divide_on_every_float(prt):
     """hw_recip (estimate + one fma Newton step, divide for the extreme exponents) replaces the 1/x of the slab and
     triangle tests; it must be the correctly rounded reciprocal for all 2^32 inputs"""
