@@ -4,9 +4,10 @@
 //   state_to_rtd / rtd_to_state   80 B/px SoA planes <-> the reference's 112 B RTD records
 //   count_kernel                  sum of samples / segments / frozen pixels (Msamples/s accounting)
 //
-// Launch geometry: 256-thread workgroups = 4 waves; each wave owns an 8x8 pixel tile (primary rays of
-// one wave walk the same BVH nodes), a workgroup a 16x16 tile; dynamic LDS (DevScene::stack_levels KiB per
-// workgroup) holds the traversal stacks.  A 1920x1080 frame is 8 160 workgroups >> 256 CUs.
+// Launch geometry: one wave per workgroup, owning an 8x8 pixel tile (primary rays of one wave walk the same
+// BVH nodes); dynamic LDS (DevScene::stack_levels x 256 B per workgroup) holds the traversal stacks.  A
+// 1920x1080 frame is 32 400 workgroups >> 256 CUs x 16 resident waves, rendered as two interleaved sets of
+// tiles on two streams (prt_api.cpp).
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -22,20 +23,21 @@ using namespace dev;
 #define PT_MIN_WAVES 4      // waves per SIMD the register allocator must leave room for (128 VGPRs)
 #endif
 #ifndef PT_BLOCK
-#define PT_BLOCK 256        // threads per workgroup
+#define PT_BLOCK 64         // threads per workgroup: ONE wave.  A workgroup's slot (LDS, dispatch) frees only when its last wave
+                            // ends, and waves over the mesh run ~3x longer than waves over a wall: one-wave groups +4 % over 256
 #endif
 
 template <unsigned MATS, bool MEDIUM>
 __global__ __launch_bounds__(PT_BLOCK, PT_MIN_WAVES) void render_kernel(const DevScene sc, const DevCamera cam, const DevState S,
                                                                         const FrameArgs fa, float4* __restrict__ fb) {
-    // workgroup tile: (PT_BLOCK / 128) x 2 waves of 8x8 pixels
-    constexpr int TILE_W = PT_BLOCK / 16, WAVES_X = TILE_W / 8;
+    // workgroup tile: 8x8 pixels per wave; 1 wave (PT_BLOCK 64), 1x2 (128) or 2x2 (256) waves per workgroup
+    constexpr int TILE_H = PT_BLOCK >= 128 ? 16 : 8, TILE_W = PT_BLOCK / TILE_H, WAVES_X = TILE_W / 8;
     const int tiles_x = (fa.width + TILE_W - 1) / TILE_W;
     const unsigned tile = blockIdx.x * fa.tile_stride + fa.tile_first;
     const int tile_x = (int)(tile % (unsigned)tiles_x), tile_y = (int)(tile / (unsigned)tiles_x);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int lx = tile_x * TILE_W + (wave % WAVES_X) * 8 + (lane & 7);
-    const int ly = tile_y * 16 + (wave / WAVES_X) * 8 + (lane >> 3);
+    const int ly = tile_y * TILE_H + (wave / WAVES_X) * 8 + (lane >> 3);
     if (lx >= fa.width || ly >= fa.rows) return;                // no barriers in this kernel
     const size_t id = (size_t)ly * (size_t)fa.width + (size_t)lx;
     const int gx = lx;
@@ -490,8 +492,8 @@ __global__ void selftest_math_kernel(int fn, const float* __restrict__ a, const 
 template <unsigned MATS, bool MEDIUM>
 static void launch_variant(const DevScene& sc, const DevCamera& cam, const DevState& S, const FrameArgs& fa, float4* fb,
                            hipStream_t stream) {
-    constexpr unsigned TILE_W = PT_BLOCK / 16;
-    const unsigned tiles_x = ((unsigned)fa.width + TILE_W - 1) / TILE_W, tiles_y = (unsigned)((fa.rows + 15) >> 4);
+    constexpr unsigned TILE_H = PT_BLOCK >= 128 ? 16 : 8, TILE_W = PT_BLOCK / TILE_H;
+    const unsigned tiles_x = ((unsigned)fa.width + TILE_W - 1) / TILE_W, tiles_y = ((unsigned)fa.rows + TILE_H - 1) / TILE_H;
     const size_t lds = (size_t)sc.stack_levels * PT_BLOCK * sizeof(unsigned);
     if (lds > 65536u)        // only the 65-level case (a tree that fills the reference's 64-entry stack to the brim)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<MATS, MEDIUM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
