@@ -27,9 +27,12 @@ using namespace dev;
                             // ends, and waves over the mesh run ~3x longer than waves over a wall: one-wave groups +4 % over 256
 #endif
 
-template <unsigned MATS, bool MEDIUM>
-__global__ __launch_bounds__(PT_BLOCK, PT_MIN_WAVES) void render_kernel(const DevScene sc, const DevCamera cam, const DevState S,
-                                                                        const FrameArgs fa, float4* __restrict__ fb) {
+// WAVES = waves per SIMD the register allocator leaves room for: 4 (128 VGPRs) is best while the tree sits in L2;
+// on a tree of tens of MB every node step is a trip to the Infinity Cache or HBM and 5 waves (96 VGPRs, more
+// spills, more latency hidden) win +13 % (871 k triangles); 6 and 8 lose again.
+template <unsigned MATS, bool MEDIUM, int WAVES>
+__global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene sc, const DevCamera cam, const DevState S,
+                                                                 const FrameArgs fa, float4* __restrict__ fb) {
     // workgroup tile: 8x8 pixels per wave; 1 wave (PT_BLOCK 64), 1x2 (128) or 2x2 (256) waves per workgroup
     constexpr int TILE_H = PT_BLOCK >= 128 ? 16 : 8, TILE_W = PT_BLOCK / TILE_H, WAVES_X = TILE_W / 8;
     const int tiles_x = (fa.width + TILE_W - 1) / TILE_W;
@@ -489,18 +492,27 @@ __global__ void selftest_math_kernel(int fn, const float* __restrict__ a, const 
 }
 
 // ---- host-side launchers -------------------------------------------------------------------------------
-template <unsigned MATS, bool MEDIUM>
-static void launch_variant(const DevScene& sc, const DevCamera& cam, const DevState& S, const FrameArgs& fa, float4* fb,
-                           hipStream_t stream) {
+template <unsigned MATS, bool MEDIUM, int WAVES>
+static void launch_variant_w(const DevScene& sc, const DevCamera& cam, const DevState& S, const FrameArgs& fa, float4* fb,
+                             hipStream_t stream) {
     constexpr unsigned TILE_H = PT_BLOCK >= 128 ? 16 : 8, TILE_W = PT_BLOCK / TILE_H;
     const unsigned tiles_x = ((unsigned)fa.width + TILE_W - 1) / TILE_W, tiles_y = ((unsigned)fa.rows + TILE_H - 1) / TILE_H;
     const size_t lds = (size_t)sc.stack_levels * PT_BLOCK * sizeof(unsigned);
-    if (lds > 65536u)        // only the 65-level case (a tree that fills the reference's 64-entry stack to the brim)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<MATS, MEDIUM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 65536u)        // only a 4-wave build with a tree that fills the reference's 64-entry stack to the brim
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<MATS, MEDIUM, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const unsigned n_tiles = tiles_x * tiles_y;
     if (fa.tile_first >= n_tiles) return;
     const unsigned grid = (n_tiles - fa.tile_first + fa.tile_stride - 1) / fa.tile_stride;      // tiles of this sub-part
-    hipLaunchKernelGGL((render_kernel<MATS, MEDIUM>), dim3(grid), dim3(PT_BLOCK), lds, stream, sc, cam, S, fa, fb);
+    hipLaunchKernelGGL((render_kernel<MATS, MEDIUM, WAVES>), dim3(grid), dim3(PT_BLOCK), lds, stream, sc, cam, S, fa, fb);
+}
+template <unsigned MATS, bool MEDIUM>
+static void launch_variant(const DevScene& sc, const DevCamera& cam, const DevState& S, const FrameArgs& fa, float4* fb,
+                           hipStream_t stream) {
+    const char* e_waves = std::getenv("PRT_WAVES");                       // 4 / 5: override (tests, experiments)
+    const int forced = e_waves ? std::atoi(e_waves) : 0;
+    const bool big = forced ? forced >= 5 : sc.n_pairs > 65536u;          // the node records alone exceed one XCD's L2
+    if (big) launch_variant_w<MATS, MEDIUM, 5>(sc, cam, S, fa, fb, stream);
+    else launch_variant_w<MATS, MEDIUM, PT_MIN_WAVES>(sc, cam, S, fa, fb, stream);
 }
 
 // Variant choice = the AOT analogue of the reference's per-scene program build (include/CL/cl_kernel.h):

@@ -233,6 +233,19 @@ def test_internal_streams_are_invisible(prt, oracle, streams, monkeypatch):
     r.close()
 
 
+@pytest.mark.parametrize("variant", ["cornell_diffuse", "cornell_media_hg", "cornell_sdf"])
+def test_five_wave_kernel_variants_match_golden(prt, oracle, variant, monkeypatch):
+    """big trees run the 96-register build of the kernel (5 waves/SIMD); forced here on the small scenes"""
+    monkeypatch.setenv("PRT_WAVES", "5")
+    g = np.load(os.path.join(GOLDEN, variant + ".npz"))
+    W, H, frames = int(g["width"]), int(g["height"]), int(g["frames"])
+    scene, cfg, cam, env, r = _setup(prt, variant, W, H)
+    r.render_frames(prt.seed_pairs(frames))
+    gstate = np.ascontiguousarray(g["state"]).view(oracle.PATH_STATE_DTYPE).reshape(-1)
+    _assert_same(oracle, gstate, g["image"], r.read_state(), r.read_framebuffer(), variant + " 5-wave build vs golden")
+    r.close()
+
+
 def test_fast_reciprocal_is_the_ieee_divide_on_every_float(prt):
     """hw_recip (estimate + one fma Newton step, divide for the extreme exponents) replaces the 1/x of the slab and
     triangle tests; it must be the correctly rounded reciprocal for all 2^32 inputs"""
