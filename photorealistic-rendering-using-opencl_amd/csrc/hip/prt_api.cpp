@@ -41,16 +41,16 @@ struct prt_ctx {
     DevState S{};
     float4* fb = nullptr;
     int32_t* d_seeds = nullptr; size_t seeds_cap = 0;
-    unsigned long long* d_counters = nullptr;     // [0] unfinished, [1..3] count_kernel, [4 + j] unfinished of sub-part j
+    unsigned long long* d_counters = nullptr;     // [0] unfinished, [1..3] count_kernel, [4 + 2j, 5 + 2j] {unfinished, waves done} of sub-part j
     // The megakernel renders the frame as n_sub interleaved sets of tiles, each on its own stream: the sets are
     // independent (pixels are), so while one set's launch drains on its slowest tiles the other fills the CUs.
     static constexpr int MAX_SUB = 4;
     int n_sub = 2;
     hipStream_t sub_stream[MAX_SUB] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t sub_ev[MAX_SUB] = {nullptr, nullptr, nullptr, nullptr};       // end of a sub-part's launch
-    hipEvent_t sub_ev0[MAX_SUB] = {nullptr, nullptr, nullptr, nullptr};      // its start (prt_render_spp times every launch)
+    hipEvent_t sub_ev[MAX_SUB][2] = {};           // end of a sub-part's launch (two in flight per sub-part)
+    hipEvent_t sub_ev0[MAX_SUB][2] = {};          // its start (prt_render_spp times every launch)
     hipEvent_t fork_ev = nullptr;
-    unsigned long long* h_unfinished = nullptr;   // pinned, MAX_SUB entries
+    unsigned long long* h_unfinished = nullptr;   // pinned, [MAX_SUB][2]: written by the last wave of a launch
     // wavefront pipeline (optional)
     int pipeline = 0;                              // 0 = megakernel, 1 = wavefront
     DevWave wv{};
@@ -92,8 +92,9 @@ extern "C" int prt_create(int device, const prt_config* cfg, prt_ctx** out) {
     c->cfg = *cfg;
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
-        (e = hipMalloc(reinterpret_cast<void**>(&c->d_counters), (4 + prt_ctx::MAX_SUB) * sizeof(unsigned long long))) != hipSuccess ||
-        (e = hipHostMalloc(reinterpret_cast<void**>(&c->h_unfinished), prt_ctx::MAX_SUB * sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipMalloc(reinterpret_cast<void**>(&c->d_counters), (4 + 2 * prt_ctx::MAX_SUB) * sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipMemset(c->d_counters, 0, (4 + 2 * prt_ctx::MAX_SUB) * sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipHostMalloc(reinterpret_cast<void**>(&c->h_unfinished), 2 * prt_ctx::MAX_SUB * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming)) != hipSuccess) {
         g_global_error = std::string("prt_create: ") + hipGetErrorString(e);
         prt_destroy(c);
@@ -102,7 +103,8 @@ extern "C" int prt_create(int device, const prt_config* cfg, prt_ctx** out) {
     if (const char* ev = std::getenv("PRT_STREAMS")) { const int k = std::atoi(ev); if (k >= 1 && k <= prt_ctx::MAX_SUB) c->n_sub = k; }
     for (int j = 0; j < c->n_sub && c->n_sub > 1; ++j)
         if ((e = hipStreamCreateWithFlags(&c->sub_stream[j], hipStreamNonBlocking)) != hipSuccess ||
-            (e = hipEventCreate(&c->sub_ev[j])) != hipSuccess || (e = hipEventCreate(&c->sub_ev0[j])) != hipSuccess) {
+            (e = hipEventCreate(&c->sub_ev[j][0])) != hipSuccess || (e = hipEventCreate(&c->sub_ev0[j][0])) != hipSuccess ||
+            (e = hipEventCreate(&c->sub_ev[j][1])) != hipSuccess || (e = hipEventCreate(&c->sub_ev0[j][1])) != hipSuccess) {
             g_global_error = std::string("prt_create: ") + hipGetErrorString(e);
             prt_destroy(c);
             return PRT_ERR_HIP;
@@ -159,8 +161,10 @@ extern "C" void prt_destroy(prt_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (int j = 0; j < prt_ctx::MAX_SUB; ++j) {
         if (c->sub_stream[j]) { (void)hipStreamSynchronize(c->sub_stream[j]); (void)hipStreamDestroy(c->sub_stream[j]); }
-        if (c->sub_ev[j]) (void)hipEventDestroy(c->sub_ev[j]);
-        if (c->sub_ev0[j]) (void)hipEventDestroy(c->sub_ev0[j]);
+        for (int k = 0; k < 2; ++k) {
+            if (c->sub_ev[j][k]) (void)hipEventDestroy(c->sub_ev[j][k]);
+            if (c->sub_ev0[j][k]) (void)hipEventDestroy(c->sub_ev0[j][k]);
+        }
     }
     if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
     if (c->h_unfinished) (void)hipHostFree(c->h_unfinished);
@@ -506,6 +510,7 @@ static FrameArgs frame_args(prt_ctx* c, uint32_t first_frame, uint32_t n, const 
     fa.block_rows = c->block_rows; fa.n_parts = c->n_parts; fa.part = c->part;
     fa.first_frame = first_frame; fa.n_frames = n; fa.seed_pairs = d_seeds; fa.spp_limit = spp;
     fa.unfinished = count ? c->d_counters : nullptr;
+    fa.unfinished_host = nullptr;
     fa.tile_first = 0; fa.tile_stride = 1;
     return fa;
 }
@@ -521,8 +526,8 @@ static int fork_streams(prt_ctx* c, int K) {
 // ... and the caller's stream continues behind them
 static int join_streams(prt_ctx* c, int K) {
     for (int j = 0; j < K; ++j) {
-        HIPCHK(c, hipEventRecord(c->sub_ev[j], c->sub_stream[j]));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->sub_ev[j], 0));
+        HIPCHK(c, hipEventRecord(c->sub_ev[j][0], c->sub_stream[j]));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->sub_ev[j][0], 0));
     }
     return PRT_OK;
 }
@@ -627,42 +632,64 @@ extern "C" int prt_render_spp(prt_ctx* c, uint32_t spp, uint32_t max_frames, con
             HIPCHK(c, hipStreamSynchronize(c->stream));
         }
     } else {
-        // every sub-part advances on its own stream until its own pixels are frozen; the host only feeds the next
-        // launch of a sub-part when the previous one has reported how many of its pixels are still running
+        // Every sub-part advances on its own stream until its own pixels are frozen.  The last wave of a launch writes
+        // the number of pixels still running to pinned host memory and clears the device counters, so there is no copy
+        // or fill kernel between launches (with the other stream's kernel filling the chip those waited ~1.7 ms for a
+        // wave slot) and the HIP events around a launch time the kernel alone.  A launch queued behind one that
+        // reported 0 (PRT_QUEUE_DEPTH=2) finds every pixel frozen and returns at once.
         if ((rc = fork_streams(c, K))) return rc;
-        uint32_t fj[prt_ctx::MAX_SUB] = {0, 0, 0, 0};
-        bool in_flight[prt_ctx::MAX_SUB] = {false, false, false, false}, done[prt_ctx::MAX_SUB] = {false, false, false, false};
-        int n_done = 0;
+        uint32_t fj[prt_ctx::MAX_SUB] = {0, 0, 0, 0};            // frames queued so far
+        uint32_t f_end[prt_ctx::MAX_SUB][2] = {};                 // ... up to the end of the launch in each slot
+        unsigned issued[prt_ctx::MAX_SUB] = {0, 0, 0, 0}, retired[prt_ctx::MAX_SUB] = {0, 0, 0, 0};
+        uint32_t f_done[prt_ctx::MAX_SUB] = {0, 0, 0, 0};        // frames after which the sub-part reported 0
+        bool stop[prt_ctx::MAX_SUB] = {false, false, false, false};
         bool exhausted = false;
-        while (n_done < K) {
-            bool progressed = false;
+        // launches queued per sub-part: 1 (the other sub-part's kernel covers the host round trip; 2 measured the same)
+        static const unsigned depth = [] { const char* e = std::getenv("PRT_QUEUE_DEPTH"); return (e && std::atoi(e) == 2) ? 2u : 1u; }();
+        const unsigned n_tiles = render_tile_count(c->width, c->rows);
+        for (int j = 0; j < K; ++j) stop[j] = (unsigned)j >= n_tiles;      // a sub-part without tiles has nothing to do
+        for (;;) {
+            bool progressed = false, busy = false;
             for (int j = 0; j < K; ++j) {
-                if (done[j]) continue;
-                if (in_flight[j]) {
-                    const hipError_t q = hipEventQuery(c->sub_ev[j]);
+                while (!stop[j] && issued[j] - retired[j] < depth && fj[j] < max_frames) {
+                    const unsigned slot = issued[j] & 1u;
+                    const uint32_t n = (max_frames - fj[j] < step) ? max_frames - fj[j] : step;
+                    FrameArgs fa = frame_args(c, 1 + fj[j], n, c->d_seeds + 2 * (size_t)fj[j], spp, true);
+                    fa.unfinished = c->d_counters + 4 + 2 * j;
+                    fa.unfinished_host = c->h_unfinished + 2 * j + slot;
+                    fa.tile_first = (uint32_t)j; fa.tile_stride = (uint32_t)K;
+                    c->h_unfinished[2 * j + slot] = ~0ull;
+                    HIPCHK(c, hipEventRecord(c->sub_ev0[j][slot], c->sub_stream[j]));
+                    c->variant = launch_render(c->sc, c->cam, c->S, fa, c->fb, c->sub_stream[j]);
+                    HIPCHK(c, hipEventRecord(c->sub_ev[j][slot], c->sub_stream[j]));
+                    ++c->stats.launches;
+                    fj[j] += n;
+                    f_end[j][slot] = fj[j];
+                    ++issued[j];
+                    progressed = true;
+                }
+                if (issued[j] != retired[j]) {
+                    busy = true;
+                    const unsigned slot = retired[j] & 1u;
+                    const hipError_t q = hipEventQuery(c->sub_ev[j][slot]);
                     if (q == hipErrorNotReady) continue;
                     HIPCHK(c, q);
-                    in_flight[j] = false; progressed = true;
                     float ms = 0.f;
-                    if (hipEventElapsedTime(&ms, c->sub_ev0[j], c->sub_ev[j]) == hipSuccess) c->stats.kernel_sum_ms += ms;
-                    if (c->h_unfinished[j] == 0) { done[j] = true; ++n_done; continue; }
-                    if (fj[j] >= max_frames) { done[j] = true; ++n_done; exhausted = true; continue; }
+                    if (hipEventElapsedTime(&ms, c->sub_ev0[j][slot], c->sub_ev[j][slot]) == hipSuccess) c->stats.kernel_sum_ms += ms;
+                    const unsigned long long left = __atomic_load_n(c->h_unfinished + 2 * j + slot, __ATOMIC_ACQUIRE);
+                    if (left == ~0ull) return fail(c, PRT_ERR_HIP, "prt_render_spp: a launch ended without reporting its unfinished pixels");
+                    ++retired[j];
+                    progressed = true;
+                    if (!stop[j]) {
+                        if (left == 0) { stop[j] = true; f_done[j] = f_end[j][slot]; }
+                        else if (f_end[j][slot] >= max_frames) { stop[j] = true; f_done[j] = max_frames; exhausted = true; }
+                    }
                 }
-                const uint32_t n = (max_frames - fj[j] < step) ? max_frames - fj[j] : step;
-                FrameArgs fa = frame_args(c, 1 + fj[j], n, c->d_seeds + 2 * (size_t)fj[j], spp, true);
-                fa.unfinished = c->d_counters + 4 + j;
-                fa.tile_first = (uint32_t)j; fa.tile_stride = (uint32_t)K;
-                HIPCHK(c, hipMemsetAsync(fa.unfinished, 0, sizeof(unsigned long long), c->sub_stream[j]));
-                HIPCHK(c, hipEventRecord(c->sub_ev0[j], c->sub_stream[j]));
-                c->variant = launch_render(c->sc, c->cam, c->S, fa, c->fb, c->sub_stream[j]);
-                HIPCHK(c, hipMemcpyAsync(&c->h_unfinished[j], fa.unfinished, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->sub_stream[j]));
-                HIPCHK(c, hipEventRecord(c->sub_ev[j], c->sub_stream[j]));
-                ++c->stats.launches;
-                fj[j] += n;
-                in_flight[j] = true; progressed = true;
             }
+            if (!busy && !progressed) break;
             if (!progressed) std::this_thread::sleep_for(std::chrono::microseconds(50));
         }
+        for (int j = 0; j < K; ++j) fj[j] = f_done[j];
         for (int j = 0; j < K; ++j) f = fj[j] > f ? fj[j] : f;
         unfinished = exhausted ? 1 : 0;
         if ((rc = join_streams(c, K))) return rc;

@@ -41,6 +41,7 @@ __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int lx = tile_x * TILE_W + (wave % WAVES_X) * 8 + (lane & 7);
     const int ly = tile_y * TILE_H + (wave / WAVES_X) * 8 + (lane >> 3);
+    static_assert(PT_BLOCK == 64, "the end-of-launch ticket counts one wave per workgroup, each with a pixel inside the frame");
     if (lx >= fa.width || ly >= fa.rows) return;                // no barriers in this kernel
     const size_t id = (size_t)ly * (size_t)fa.width + (size_t)lx;
     const int gx = lx;
@@ -93,7 +94,20 @@ __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene 
     if (fa.unfinished) {
         const bool unfinished = !(fa.spp_limit && st.reset && st.samples >= fa.spp_limit);
         const unsigned long long m = __ballot(unfinished);
-        if (m && lane == (int)__builtin_ctzll(__ballot(1))) atomicAdd(fa.unfinished, (unsigned long long)__popcll(m));
+        if (lane == (int)__builtin_ctzll(__ballot(1))) {
+            // returning atomic: its value is back only once the add has been performed at the device's coherence point
+            const unsigned long long before = m ? atomicAdd(fa.unfinished, (unsigned long long)__popcll(m)) : 0ull;
+            if (fa.unfinished_host && before != ~0ull) {       // (never equal: the test orders the ticket behind the add without a
+                // fence -- a device-scope fence writes back and invalidates this XCD's L2, 2.5 % when every wave does it)
+                // The last wave of the launch hands the total to the host and leaves the counters clean for the next launch
+                // (every 8x8 tile holds at least one pixel of the frame, so every wave of the grid gets here).
+                if (atomicAdd(fa.unfinished + 1, 1ull) == (unsigned long long)gridDim.x * (PT_BLOCK / 64) - 1ull) {
+                    const unsigned long long total = atomicExch(fa.unfinished, 0ull);
+                    atomicExch(fa.unfinished + 1, 0ull);
+                    *reinterpret_cast<volatile unsigned long long*>(fa.unfinished_host) = total;   // visible to the host at kernel end
+                }
+            }
+        }
     }
 }
 
@@ -559,6 +573,11 @@ void launch_wf_pass(const DevScene& sc, const DevCamera& cam, const DevState& S,
     const size_t lds = (size_t)sc.stack_levels * 256 * sizeof(unsigned);
     if (lds > 65536u) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wf_trav_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(wf_trav_kernel, dim3(trav_blocks), dim3(256), lds, stream, sc, wv, pass);
+}
+
+unsigned render_tile_count(int width, int rows) {
+    constexpr unsigned TILE_H = PT_BLOCK >= 128 ? 16 : 8, TILE_W = PT_BLOCK / TILE_H;
+    return (((unsigned)width + TILE_W - 1) / TILE_W) * (((unsigned)rows + TILE_H - 1) / TILE_H);
 }
 
 void make_dev_camera(const prt_camera& in, DevCamera& out) {

@@ -14,6 +14,8 @@ const char* launch_render(const DevScene& sc, const DevCamera& cam, const DevSta
 // one wavefront pass: shade (resume / start, suspend at deep walks) + traverse the compacted queue
 void launch_wf_pass(const DevScene& sc, const DevCamera& cam, const DevState& S, const DevWave& wv, const FrameArgs& fa, float4* fb,
                     unsigned pass, unsigned trav_blocks, hipStream_t stream);
+// workgroups (tiles) launch_render uses for a width x rows frame part
+unsigned render_tile_count(int width, int rows);
 // per-camera part of createCamRay (camera.cl:19-28), on the host with the arithmetic of pt_device.h
 void make_dev_camera(const prt_camera& in, DevCamera& out);
 void launch_state_to_rtd(const DevState& S, prt_path_state* out, size_t n, hipStream_t stream);

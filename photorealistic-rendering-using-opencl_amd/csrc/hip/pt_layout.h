@@ -125,6 +125,9 @@ struct FrameArgs {
     const int32_t* seed_pairs;              // device, 2 * n_frames
     uint32_t spp_limit;
     unsigned long long* unfinished;         // device counter: pixels not yet frozen (spp mode), or null
+    unsigned long long* unfinished_host;    // null: the host reads `unfinished` itself.  Else `unfinished` is a pair {count, waves
+                                            // done}; the last wave of the launch writes the count here (pinned host memory) and
+                                            // zeroes the pair for the next launch: no copy / fill kernels between launches
     uint32_t tile_first, tile_stride;       // this launch covers the tiles tile_first + k * tile_stride (sub-part of the frame)
 };
 
