@@ -115,7 +115,10 @@ def main():
     if a.env == "sky":
         r.upload_envmap(prt.make_sky(1024, 512))
     r.set_camera(cam)
-    stream = torch.cuda.current_stream()
+    # all GPU work of a step -- libprt's launches, the device-to-device copy of the rows, torch's merge -- is ordered
+    # on ONE explicit stream (torch's default stream is the null handle, which libprt takes as "use your own")
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
     r.set_stream(stream.cuda_stream)
     if world == 1:
         r.resize(W, H)

@@ -167,7 +167,9 @@ int prt_read_framebuffer(prt_ctx* ctx, float* rgba);
  * filmic Reinhard with white point 1.2, smoothstep, gamma 2.2) applied on the device; 8-bit RGBA out, rows in
  * framebuffer order (what glReadPixels returns, include/GL/cl_gl_interop.h:147-150). */
 int prt_tonemap_rgba8(prt_ctx* ctx, uint8_t* rgba);
-/* same, device to device, into caller-owned device memory (e.g. a torch tensor) on the context's stream */
+/* same, device to device, into caller-owned device memory (e.g. a torch tensor).  Asynchronous on a stream given
+ * with prt_set_stream (ordered with the caller's other work there); complete on return otherwise (the context's own
+ * stream is private and non-blocking: nothing of the caller's is ordered against it). */
 int prt_copy_framebuffer_to_device(prt_ctx* ctx, void* device_rgba);
 
 /* r_flat, in the reference's 112-byte RTD layout (checkpoint / resume / parity checks). */

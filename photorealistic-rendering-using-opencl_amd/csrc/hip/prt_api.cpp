@@ -752,6 +752,9 @@ extern "C" int prt_copy_framebuffer_to_device(prt_ctx* c, void* device_rgba) {
     if (!device_rgba || !c->have_size) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_copy_framebuffer_to_device: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(device_rgba, c->fb, c->npix * 16, hipMemcpyDeviceToDevice, c->stream));
+    // on a caller's stream (prt_set_stream) the copy is ordered like any other work of the caller; the context's own
+    // stream is private and non-blocking, nothing of the caller's could wait for it: finish the copy before returning
+    if (c->stream == c->own_stream) HIPCHK(c, hipStreamSynchronize(c->stream));
     return PRT_OK;
 }
 

@@ -1,12 +1,13 @@
 """GPU parity tests: the HIP path behind the C ABI (libprt.so) against the CPU oracle
 (oracle/pt_oracle.c) and against the golden fixtures produced by the reference build.
 Bar: bit-identical path state (every field of the 112-byte RTD record) and framebuffer."""
+import importlib
 import os
 
 import numpy as np
 import pytest
 
-from conftest import ALPHA_VARIANTS, GOLDEN, VARIANTS
+from conftest import ALPHA_VARIANTS, GOLDEN, PKG_NAME, VARIANTS
 
 pytestmark = pytest.mark.gpu
 
@@ -147,6 +148,42 @@ def test_interleaved_row_blocks_union_equals_full_frame(prt, oracle):
         got_state[rows] = rt.read_state().reshape(len(rows), W)
         rt.close()
     _assert_same(oracle, full_state.reshape(-1).view(oracle.PATH_STATE_DTYPE), full_img, got_state.reshape(-1), got_img, "row blocks")
+
+
+def test_device_side_merge_of_row_block_parts_with_torch(prt, oracle):
+    """the multi-GPU merge path of bench.py on one GPU: every part copies its rows device-to-device into a torch
+    tensor (prt_copy_framebuffer_to_device), the parts are summed into zero-padded full frames (parallel.merge_on_rank0
+    without a process group) -- both with the context's own stream and with a torch stream handed to prt_set_stream"""
+    import torch
+    par = importlib.import_module(PKG_NAME + ".parallel")
+    W, H, frames, parts = 72, 50, 40, 3
+    scene, cfg, cam, env, r = _setup(prt, "cornell_diffuse", W, H)
+    seeds = prt.seed_pairs(frames)
+    r.render_frames(seeds)
+    full = r.read_framebuffer()
+    r.close()
+    for use_torch_stream in (False, True):
+        total = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+        stream = torch.cuda.Stream() if use_torch_stream else None
+        for part in range(parts):
+            rp = prt.Renderer(cfg, device=0)
+            rp.upload_scene(scene)
+            rp.set_camera(cam)
+            if stream is not None:
+                rp.set_stream(stream.cuda_stream)
+            rp.set_row_blocks(W, H, 16, parts, part)
+            rows = par.rows_of_rank(H, parts, part)
+            tile = torch.zeros((len(rows), W, 4), dtype=torch.float32, device="cuda")
+            if stream is not None:
+                stream.wait_stream(torch.cuda.current_stream())          # the zero fill above
+            rp.render_frames(seeds)                                      # asynchronous
+            rp.copy_framebuffer_to_device(tile.data_ptr())
+            if stream is not None:
+                torch.cuda.current_stream().wait_stream(stream)
+            total += par.merge_on_rank0(tile, rows, H, W, None)
+            torch.cuda.synchronize()
+            rp.close()
+        assert oracle.images_equal(full, total.cpu().numpy()), "merged parts differ (torch stream: %s)" % use_torch_stream
 
 
 def test_camera_change_and_reset(prt, oracle):
