@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = N x the pixels (frame x sqrt(N) per dimension), strong = the base frame split N ways")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify", action="store_true",
+                    help="N > 1: after the timed steps rank 0 renders the whole frame alone and compares it bit for bit with the merged one")
     a = ap.parse_args()
 
     import numpy as np
@@ -128,6 +130,7 @@ def main():
         r.set_row_blocks(W, H, par.BLOCK_ROWS, world, rank)
         tile = torch.zeros((len(my_rows), W, 4), dtype=torch.float32, device="cuda")
 
+    merged = [None]
     kernel_ms = 0.0          # wall time of the GPU work of the timed steps (HIP events around all of it)
     kernel_sum_ms = 0.0      # sum of the durations of the individual launches (HIP events around each)
     launches = 0
@@ -139,7 +142,7 @@ def main():
         r.render_spp(spp, seeds)
         if world > 1:
             r.copy_framebuffer_to_device(tile.data_ptr())
-            par.merge_on_rank0(tile, my_rows, H, W, dist)
+            merged[0] = par.merge_on_rank0(tile, my_rows, H, W, dist)
         if timed:
             st = r.stats()
             kernel_ms += st.kernel_ms
@@ -164,6 +167,22 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+
+    verified = None
+    if a.verify and world > 1:
+        torch.cuda.synchronize()
+        if rank == 0:
+            r1 = prt.Renderer(cfg, device=local_rank)
+            r1.upload_scene(scene)
+            if a.env == "sky":
+                r1.upload_envmap(prt.make_sky(1024, 512))
+            r1.set_camera(cam)
+            r1.resize(W, H)
+            r1.render_spp(spp, seeds)
+            alone = r1.read_framebuffer()
+            r1.close()
+            verified = bool(np.array_equal(alone.view(np.uint32), merged[0].cpu().numpy().view(np.uint32)))
+        dist.barrier()
 
     counts = r.counts(spp)
     seg = torch.tensor([float(counts.segments), float(counts.samples), kernel_ms, float(launches)], dtype=torch.float64, device="cuda")
@@ -223,6 +242,8 @@ def main():
                                  "launches x avg_launch_ms ~ %d x kernel_wall_ms" % (concurrent, concurrent),
                          "gsegments_per_s": round(own_segments * steps / (kernel_ms * 1e-3) / 1e9, 4) if kernel_ms > 0 else 0.0},
         }
+        if verified is not None:
+            out["config"]["merged_frame_equals_single_gpu_render"] = verified
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(prt, a)
             ref = cpu_reference_build(prt, a)
