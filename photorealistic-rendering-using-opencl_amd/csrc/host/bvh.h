@@ -21,7 +21,8 @@ using cl_BVHnode = prt_bvh_node;
 class BVH {
 public:
     // traversal_cost <= 0 picks the measured optimum: 1 for small meshes (teapot: fatter leaves are monotonically
-    // slower on MI355X), 2.5 from 64 k triangles up (871 k-triangle mesh: +9 %, the tree is two levels shallower)
+    // slower on MI355X), 1.5 from 64 k triangles up (871 k-triangle mesh, 4K frame: 216 / 219 / 211 / 196 / 182 Msamples/s at cost 1 / 1.5 / 2 / 2.5 / 3.5
+    // with the 5-wave kernel; with the 4-wave kernel of earlier in the round 2.5 was the optimum)
     explicit BVH(const std::shared_ptr<IO::ModelLoader>& ml, unsigned max_leaf_size = 16, float traversal_cost = 0.0f);
     std::unique_ptr<std::vector<uint64_t>> GetPrimitiveIndices() const;
     std::unique_ptr<std::vector<cl_BVHnode>> PrepareData() const;
