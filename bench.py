@@ -257,10 +257,10 @@ def main():
 
 def cpu_baseline(prt, a):
     """oracle/pt_oracle.c timed on the host cores: 960x540 (1/2 of the frame in each dimension,
-    same camera) at 96 spp of the same scene -- about 10-30 s of CPU work on the GPU box."""
+    same camera) at 192 spp of the same scene -- about 15 s of CPU work on the GPU box."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_api as O
-    W, H, spp = 960, 540, 96
+    W, H, spp = 960, 540, 192
     try:
         cores = len(os.sched_getaffinity(0))
     except Exception:
