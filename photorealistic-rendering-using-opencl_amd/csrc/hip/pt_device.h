@@ -301,15 +301,18 @@ PT_DEV TravRes walk(const DevScene& sc, const bool ANY_HIT, const TravReq& rq, c
         const PairTest pt = test_pair(d, p, res.t);
         const uint4 meta = d.meta;
         bool go0 = pt.go0, go1 = pt.go1;
-        if (go0 && meta.y != 0xFFFFFFFFu) {                      // left child is a leaf
-            for (unsigned i = meta.x; i < meta.x + meta.y; ++i)
-                if (hit_triangle(sc.tri_geom, i, ray, res.t, res.th)) { res.found = true; if (ANY_HIT) return res; }
-            go0 = false;
-        }
-        if (go1 && meta.w != 0xFFFFFFFFu) {
-            for (unsigned i = meta.z; i < meta.z + meta.w; ++i)
-                if (hit_triangle(sc.tri_geom, i, ray, res.t, res.th)) { res.found = true; if (ANY_HIT) return res; }
-            go1 = false;
+        const bool hit_leaf0 = go0 & (meta.y != 0xFFFFFFFFu), hit_leaf1 = go1 & (meta.w != 0xFFFFFFFFu);
+        if (hit_leaf0 | hit_leaf1) {                             // one region: a step through two inner children skips it in one branch
+            if (hit_leaf0) {                                     // left child is a leaf
+                for (unsigned i = meta.x; i < meta.x + meta.y; ++i)
+                    if (hit_triangle(sc.tri_geom, i, ray, res.t, res.th)) { res.found = true; if (ANY_HIT) return res; }
+                go0 = false;
+            }
+            if (hit_leaf1) {
+                for (unsigned i = meta.z; i < meta.z + meta.w; ++i)
+                    if (hit_triangle(sc.tri_geom, i, ray, res.t, res.th)) { res.found = true; if (ANY_HIT) return res; }
+                go1 = false;
+            }
         }
         if (go0 != go1) {
             node = go0 ? meta.x : meta.z;
