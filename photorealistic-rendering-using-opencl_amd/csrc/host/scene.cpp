@@ -34,6 +34,11 @@ Mesh default_mesh() {
     return m;
 }
 
+// `1 << n` of the reference's parser (include/Scene/scene.h:90-93,101) narrowed to the field it lands in; a shift count
+// a scene file should never hold (negative, or past the field) gives 0 instead of undefined behaviour
+template <typename T>
+static T shifted_bit(int n) { return (n >= 0 && n < (int)(8 * sizeof(T))) ? (T)(1u << n) : (T)0; }
+
 static uint8_t lobes_for_type(uint16_t t, uint8_t current) {
     // scene.h:99-116 / :223-240 -- first matching branch wins, no branch leaves lobes untouched
     if (t & PRT_MAT_LIGHT) return PRT_LOBE_NULL;
@@ -52,9 +57,9 @@ void host_scene::parse_material(const void* jv, Material& m) {
         for (size_t p = 0; p < c.Size() && p < 4; ++p) m.color[p] = c[p].GetFloat();
     }
     if (d.HasMember("roughness") && d["roughness"].IsNumber()) m.roughness = d["roughness"].GetFloat();
-    if (d.HasMember("dist") && d["dist"].IsInt()) m.dist = (uint8_t)(1 << d["dist"].GetInt());
+    if (d.HasMember("dist") && d["dist"].IsInt()) m.dist = shifted_bit<uint8_t>(d["dist"].GetInt());
     if (d.HasMember("type") && d["type"].IsInt()) {
-        m.t = (uint16_t)(1 << d["type"].GetInt());
+        m.t = shifted_bit<uint16_t>(d["type"].GetInt());
         m.lobes = lobes_for_type(m.t, m.lobes);
         if (m.t & (PRT_MAT_DIEL | PRT_MAT_ROUGH_DIEL)) {
             m.eta[0] = 1.5121f; m.eta[1] = 1.5180f; m.eta[2] = 1.5337f; m.eta[3] = 0.0f;  // BK7_eta, material.h:79
@@ -153,7 +158,7 @@ void host_scene::load_text(const std::string& text) {
             Mesh& m = cpu_meshes[at];
             m.t = PRT_GEOM_SDF;
             if (arr[i].HasMember("pos") && arr[i]["pos"].IsArray()) read3(arr[i]["pos"], m.pos);
-            if (arr[i].HasMember("type") && arr[i]["type"].IsInt()) m.t |= (uint8_t)(1 << arr[i]["type"].GetInt());
+            if (arr[i].HasMember("type") && arr[i]["type"].IsInt()) m.t |= shifted_bit<uint8_t>(arr[i]["type"].GetInt());
             if (arr[i].HasMember("params") && arr[i]["params"].IsArray())
                 for (size_t p = 0; p < arr[i]["params"].Size() && p < 16; ++p) m.joker[p] = arr[i]["params"][p].GetFloat();
             if (arr[i].HasMember("material") && arr[i]["material"].IsObject()) parse_material(&arr[i]["material"], m.mat);

@@ -134,6 +134,17 @@ def test_obj_reader_and_soup_roundtrip(prt, tmp_path):
     assert lib.prth_convert_model(b"/nonexistent.obj", str(soup).encode(), err, 256) != 0
 
 
+def test_malformed_scene_text_is_an_error_not_a_crash(prt):
+    """truncated / mistyped scene files come back as load errors; out-of-range `type` / `dist` exponents (the
+    reference shifts by them unchecked, include/Scene/scene.h:90-101) give an empty bit, not undefined behaviour"""
+    for text in ["", "{", "[1,2,3]", '{"scene":{"spheres":[{"pos":[1],"radius":"x"}],"quads":[{}]}}']:
+        with pytest.raises(prt.PrtError):
+            prt.HostScene(text, text=True)
+    sc = prt.HostScene('{"scene":{"sdfs":[{"type":99,"params":[1,2,3,4]}],"spheres":[{"pos":[0,3,0],"radius":0.5,'
+                       '"material":{"color":[5,5,5],"type":0,"dist":-3}}]}}', text=True)
+    assert list(sc.desc.object_count)[:2] == [1, 1]
+
+
 def test_obj_without_normals_gets_smooth_normals(prt, tmp_path):
     """assimp's GenSmoothNormals rule (the reference imports with aiProcessPreset_TargetRealtime_Quality): a vertex
     gets the normalised sum of the unit normals of the faces meeting at its position; faces folded back by more
