@@ -364,6 +364,35 @@ def test_traversal_stack_limit_is_the_references(prt, levels, ok):
     r.close()
 
 
+@pytest.mark.parametrize("damage", ["child_out_of_range", "cycle", "leaf_range", "primitive_index"])
+def test_malformed_bvh_is_refused_at_upload(prt, damage):
+    """the kernels index the node / triangle buffers unchecked, so prt_upload_scene is where a broken tree must stop"""
+    import ctypes as C
+    scene = prt.HostScene("cornell_diffuse.json")
+    nodes, verts, normals, idx = _chain_bvh(4)
+    if damage == "child_out_of_range":
+        nodes[0]["first"] = len(nodes) - 1
+    elif damage == "cycle":
+        inner = [i for i in range(1, len(nodes)) if not nodes[i]["leaf"]]
+        nodes[inner[-1]]["first"] = 0                      # points back at the root's... node 0 and 1
+    elif damage == "leaf_range":
+        leaf = [i for i in range(len(nodes)) if nodes[i]["leaf"]][-1]
+        nodes[leaf]["count"] = 1000
+    elif damage == "primitive_index":
+        idx[3] = 10 ** 6
+    desc = prt.SceneDesc.from_buffer_copy(bytes(scene.desc))
+    desc.vertices = verts.ctypes.data_as(C.c_void_p)
+    desc.normals = normals.ctypes.data_as(C.c_void_p)
+    desc.primitive_indices = idx.ctypes.data_as(C.c_void_p)
+    desc.triangle_count = len(idx)
+    desc.bvh_nodes = nodes.ctypes.data_as(C.c_void_p)
+    desc.bvh_node_count = len(nodes)
+    r = prt.Renderer(scene.config(), device=0)
+    with pytest.raises(prt.PrtError):
+        r.upload_scene(desc)
+    r.close()
+
+
 def test_dragon_standin_matches_oracle(prt, oracle):
     """871 k triangles, BVH depth 23: deep stacks (LDS + scratch levels), MALL-resident geometry"""
     prt.ensure_dragon_standin()
