@@ -83,6 +83,10 @@ extern "C" int prt_create(int device, const prt_config* cfg, prt_ctx** out) {
     }
     if (device < 0 || device >= n) { g_global_error = "prt_create: device ordinal out of range"; return PRT_ERR_INVALID_ARGUMENT; }
     if (cfg->light_count > PRT_MAX_LIGHTS) { g_global_error = "prt_create: too many lights"; return PRT_ERR_INVALID_ARGUMENT; }
+    if (cfg->marching_steps < 0 || cfg->marching_steps > 65536 || cfg->shadow_marching_steps < 0 || cfg->shadow_marching_steps > 65536) {
+        g_global_error = "prt_create: MARCHING_STEPS / SHADOW_MARCHING_STEPS outside 0..65536 (they bound a loop every lane runs)";
+        return PRT_ERR_INVALID_ARGUMENT;
+    }
     if (cfg->geom_flags & PRT_GEOM_BOX) {
         g_global_error = "prt_create: box primitives never render in the reference (geometry/box.cl is not included, SURVEY.md s9-Q10)";
         return PRT_ERR_UNSUPPORTED;

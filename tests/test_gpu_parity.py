@@ -236,6 +236,10 @@ def test_errors_are_reported_not_fatal(prt):
         prt.Renderer(bad, device=0)
     with pytest.raises(prt.PrtError):
         prt.Renderer(cfg, device=4096)
+    endless = prt.Config.from_buffer_copy(bytes(cfg))
+    endless.marching_steps = 2 ** 31 - 1
+    with pytest.raises(prt.PrtError, match="MARCHING_STEPS"):
+        prt.Renderer(endless, device=0)
     r.close()
     # box primitives: geometry/box.cl is never included by the reference's kernel, they cannot render there either
     import json
