@@ -296,6 +296,28 @@ PT_DEV TravRes walk(const DevScene& sc, const bool ANY_HIT, const TravReq& rq, c
     // branches (scalar mask work, free next to the vector pipe) rather than selects.
     unsigned node = 0;
     unsigned sp = 0;
+    {
+        // The step at the root, which every lane of the wave takes, reads its node through the scalar cache (the address
+        // is uniform): no vector-memory instruction, and the 6 rays in 10 that miss both of the root's children never
+        // issue one in this walk.  (All 64 lanes fetching one 64 B node is the heaviest load the texture-data path sees:
+        // it is 60 % busy in this kernel.)  A root with a leaf child that is hit takes the general loop from node 0.
+        const PairData d = load_pair(sc.pairs, 0u);
+        const PairTest pt = test_pair(d, p, res.t);
+        const uint4 meta = d.meta;
+        if (!((pt.go0 & (meta.y != 0xFFFFFFFFu)) | (pt.go1 & (meta.w != 0xFFFFFFFFu)))) {
+            if (pt.go0 != pt.go1) {
+                node = pt.go0 ? meta.x : meta.z;
+            } else if (pt.go0) {
+                unsigned nearc = meta.x, farc = meta.z;
+                if (pt.entry0 > pt.entry1) { nearc = meta.z; farc = meta.x; }
+                stack.lds[0] = farc;
+                sp = 1;
+                node = nearc;
+            } else {
+                return res;                                      // missed both: the stack is empty, the walk is over
+            }
+        }
+    }
     for (;;) {
         const PairData d = load_pair(sc.pairs, node);
         const PairTest pt = test_pair(d, p, res.t);
