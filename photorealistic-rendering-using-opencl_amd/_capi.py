@@ -125,6 +125,14 @@ def load_library(path=None):
     p = path or LIB_PATH
     if not os.path.exists(p):
         raise RuntimeError("libprt.so not built: run `python __graft_entry__.py build` (%s)" % p)
+    # PyTorch-ROCm ships its own copy of the HIP runtime.  Two copies in one process do not share the device: the one
+    # that initialises second reports "no ROCm-capable device".  Loading torch FIRST makes libprt.so's libamdhip64
+    # dependency resolve to the copy that is already there, so every Python process that might use both (bench.py,
+    # build() followed by smoke(), tests that hand torch tensors to libprt) gets one runtime.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     lib = C.CDLL(p)
     for name, res, args in PRT_API + PRTH_API:
         fn = getattr(lib, name)          # AttributeError if the export is missing

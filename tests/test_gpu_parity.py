@@ -186,6 +186,20 @@ def test_device_side_merge_of_row_block_parts_with_torch(prt, oracle):
         assert oracle.images_equal(full, total.cpu().numpy()), "merged parts differ (torch stream: %s)" % use_torch_stream
 
 
+def test_build_then_smoke_in_one_process_and_torch_after_libprt():
+    """PyTorch-ROCm carries its own HIP runtime; two runtimes in one process do not share the device, so the package
+    loads torch before libprt.so.  Fresh processes: build() + smoke() back to back, and torch used after a context"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import __graft_entry__ as g, importlib; g.build(); g.smoke(); "
+            "pkg = importlib.import_module(g.PKG_NAME); import torch; assert torch.cuda.is_available(); "
+            "r = pkg.Renderer(pkg.HostScene('cornell_coat.json').config(), device=0); r.close(); "
+            "assert torch.zeros(4, device='cuda').sum().item() == 0; print('both runtimes fine')")
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert out.returncode == 0 and "both runtimes fine" in out.stdout, out.stdout[-2000:]
+
+
 def test_camera_change_and_reset(prt, oracle):
     W, H = 56, 40
     scene, cfg, cam, env, r = _setup(prt, "cornell_coat", W, H)
