@@ -524,7 +524,8 @@ static void launch_variant(const DevScene& sc, const DevCamera& cam, const DevSt
                            hipStream_t stream) {
     const char* e_waves = std::getenv("PRT_WAVES");                       // 4 / 5: override (tests, experiments)
     const int forced = e_waves ? std::atoi(e_waves) : 0;
-    const bool big = forced ? forced >= 5 : sc.n_pairs > 65536u;          // the node records alone exceed one XCD's L2
+    // 5 waves where latency rules: the node records alone exceed one XCD's L2, or the scene raymarches SDFs (+11 %)
+    const bool big = forced ? forced >= 5 : (sc.n_pairs > 65536u || sc.n_sdfs != 0u);
     if (big) launch_variant_w<MATS, MEDIUM, 5>(sc, cam, S, fa, fb, stream);
     else launch_variant_w<MATS, MEDIUM, PT_MIN_WAVES>(sc, cam, S, fa, fb, stream);
 }
