@@ -149,13 +149,10 @@ int prt_render_frames(prt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, con
 int prt_render_spp(prt_ctx* ctx, uint32_t spp, uint32_t max_frames, const int32_t* seed_pairs,
                    uint32_t* frames_used);
 
-/* Execution pipeline.  0 (default) = megakernel: one lane owns a pixel, the frame loop and the BVH walks run
- * inside the kernel, path state in registers.  1 = wavefront: passes of a shading kernel (suspends a pixel at
- * every walk that really enters the tree; per-pixel state, hit cache and a small continuation record in HBM)
- * and a lean 64-VGPR traversal kernel over the compacted ray queue.  Same results bit for bit; the megakernel
- * is faster on every BASELINE config measured so far.  Env PRT_PIPELINE=wavefront sets the
- * default of new contexts. */
-int prt_set_pipeline(prt_ctx* ctx, int pipeline);
+/* Scheduling knob of the render kernel (no counterpart in the reference; results do not depend on it, tests check
+ * that): a wave ends a BVH-walk phase once fewer than `lanes` of its 64 lanes are still walking; the lanes cut off
+ * resume in the wave's next phase.  1 = every walk runs to its end (lock step), default 8 (PRT_WALK_MIN_LANES). */
+int prt_set_walk_min_lanes(prt_ctx* ctx, uint32_t lanes);
 
 int prt_synchronize(prt_ctx* ctx);
 

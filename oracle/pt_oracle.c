@@ -234,12 +234,29 @@ static inline void intersectNode(const prt_bvh_node* node, const RayPre* p, floa
 }
 
 #define PTO_STACK 256
+#ifdef PTO_TRACE
+/* development aid (tools/walk_sim.py): node steps of each BVH walk of a pixel-frame.  Not part of the checker build. */
+uint8_t* pto_trace_buf = 0;                 /* [pixel][frame][4] = steps of W1, W2, W3 (255 = the product would not walk), flags */
+static __thread uint8_t* pto_tr_cur = 0;
+static __thread int pto_tr_closest = 0, pto_tr_prev_probe = 0;
+static inline void pto_tr_record(int any_hit, unsigned steps) {
+    if (!pto_tr_cur) return;
+    int slot = any_hit ? 2 : (pto_tr_closest++ ? 1 : 0);
+    pto_tr_cur[slot] = (uint8_t)(steps > 254u ? 254u : steps);
+}
+#define PTO_TR_RET(x) do { pto_tr_record(any_hit, steps); return (x); } while (0)
+#else
+#define PTO_TR_RET(x) return (x)
+#endif
 /* kernels/geometry/bvh.cl:117-206 (closest hit) and :28-114 (any hit), one body */
 static int traverse_any(Scene* sc, Ray* ray, int any_hit) {
     const prt_bvh_node* stack[PTO_STACK];
     int stackSize = 0, maxStack = 0;
     const prt_bvh_node* node = &sc->nodes[0];
     const RayPre pre = ray_pre(ray);
+#ifdef PTO_TRACE
+    unsigned steps = 0;
+#endif
     if (node->is_leaf) {
         int res = 0;
         for (uint32_t i = node->first_child_or_primitive; i < node->first_child_or_primitive + node->primitive_count; ++i) {
@@ -250,6 +267,9 @@ static int traverse_any(Scene* sc, Ray* ray, int any_hit) {
         return res;
     }
     for (;;) {
+#ifdef PTO_TRACE
+        ++steps;
+#endif
         uint32_t first_child = node->first_child_or_primitive;
         const prt_bvh_node* child[2] = { &sc->nodes[first_child + 0], &sc->nodes[first_child + 1] };
         float entry[2], exit_[2];
@@ -262,11 +282,11 @@ static int traverse_any(Scene* sc, Ray* ray, int any_hit) {
                 if (child[k]->is_leaf) {
                     uint32_t b = child[k]->first_child_or_primitive, e = b + child[k]->primitive_count;
                     if (any_hit) {
-                        for (uint32_t i = b; i < e; ++i) if (intersectTriangle(sc, ray, i)) return 1;
+                        for (uint32_t i = b; i < e; ++i) if (intersectTriangle(sc, ray, i)) PTO_TR_RET(1);
                     } else {
                         int res = 0;
                         for (uint32_t i = b; i < e; ++i) res |= intersectTriangle(sc, ray, i);
-                        if (res && ray->t <= EPS) return 1;
+                        if (res && ray->t <= EPS) PTO_TR_RET(1);
                     }
                     go[k] = 0;
                 }
@@ -290,7 +310,7 @@ static int traverse_any(Scene* sc, Ray* ray, int any_hit) {
     }
     if (any_hit) { if (maxStack > sc->max_shadow_stack) sc->max_shadow_stack = maxStack; }
     else if (maxStack > sc->max_stack) sc->max_stack = maxStack;
-    return 0;
+    PTO_TR_RET(0);
 }
 
 /* ---- kernels/geometry/sphere.cl:5-41 ---- */
@@ -489,6 +509,17 @@ static int intersect_scene(Scene* sc, Ray* ray, int* mesh_id) {
 static int shadow(Scene* sc, Ray* ray) {
     const float maxDist = ray->t;
     Ray temp_ray = *ray;
+#ifdef PTO_TRACE
+    if (pto_tr_cur) {                       /* the product tests the primitives first and skips the walk when they occlude */
+        Ray pr = *ray; int occ = 0;
+        if (sc->cfg->geom_flags & PRT_GEOM_SPHERE)
+            for (uint32_t i = 0; i < sc->counts[0]; ++i) if (intersect_sphere(&pr, &sc->meshes[i]) && pr.t < maxDist) occ = 1;
+        uint32_t q = sc->counts[0] + sc->counts[1];
+        if (sc->cfg->geom_flags & PRT_GEOM_QUAD)
+            for (uint32_t i = 0; i < sc->counts[3]; ++i) if (intersect_quad(&sc->meshes[q++], &pr) && pr.t < maxDist) occ = 1;
+        if (occ) pto_tr_cur[3] |= 1;
+    }
+#endif
     if (traverse_any(sc, ray, 1)) { *ray = temp_ray; return 0; }
     if (sc->cfg->geom_flags & PRT_GEOM_SPHERE) {
         for (uint32_t i = 0; i < sc->counts[0]; ++i)
@@ -1212,6 +1243,10 @@ static void render_pixel(Scene* sc, const prt_camera* cam, int width, int height
     ray.dir = vload(st->dir);
     ray.t = st->dist;
     ray.time = st->time;
+#ifdef PTO_TRACE
+    const int tr_restart = st->reset || st->samples == 0;
+    if (pto_tr_cur) { pto_tr_cur[0] = pto_tr_cur[1] = pto_tr_cur[2] = 255; pto_tr_cur[3] = 0; pto_tr_closest = 0; }
+#endif
     if (st->reset || st->samples == 0) {
         ++st->samples;
         st->total = 0; st->diff = 0; st->spec = 0; st->trans = 0; st->scatters = 0;
@@ -1222,6 +1257,15 @@ static void render_pixel(Scene* sc, const prt_camera* cam, int width, int height
     }
     float r[4];
     radiance(sc, &ray, st, &rng, r);
+#ifdef PTO_TRACE
+    if (pto_tr_cur) {
+        if (!tr_restart && pto_tr_prev_probe) pto_tr_cur[0] = 255;      /* hit cache: W1 of this segment was the previous probe */
+        if (pto_tr_cur[3] & 1) pto_tr_cur[2] = 255;
+        pto_tr_prev_probe = pto_tr_cur[1] != 255;
+        if (tr_restart) pto_tr_cur[3] |= 2;
+        if (st->reset) pto_tr_cur[3] |= 4;                               /* path ended in this segment */
+    }
+#endif
     st->acc[0] += r[0]; st->acc[1] += r[1]; st->acc[2] += r[2]; st->acc[3] += r[3];
     st->origin[0] = ray.origin.x; st->origin[1] = ray.origin.y; st->origin[2] = ray.origin.z;   /* rayToTemp, main.cl:28 */
     st->dir[0] = ray.dir.x; st->dir[1] = ray.dir.y; st->dir[2] = ray.dir.z;
@@ -1253,8 +1297,14 @@ static void* worker_main(void* arg) {
         const int gy = j->row0 + (ly / B * NP + j->part) * B + ly % B;
         prt_path_state* st = &j->state[id];
         float* px = j->out_rgba + 4 * id;
+#ifdef PTO_TRACE
+        pto_tr_prev_probe = 0;
+#endif
         for (uint32_t f = 0; f < j->n_frames; ++f) {
             if (j->spp_limit && st->reset && st->samples >= j->spp_limit) break;
+#ifdef PTO_TRACE
+            pto_tr_cur = pto_trace_buf ? pto_trace_buf + ((size_t)id * j->n_frames + f) * 4 : 0;
+#endif
             render_pixel(&w->scene, j->camera, j->width, j->full_height, gx, gy, j->first_frame + f,
                          j->seed_pairs[2 * f], j->seed_pairs[2 * f + 1], st, px);
         }

@@ -183,10 +183,8 @@ class Renderer:
                   "prt_render_spp")
         return used.value
 
-    def set_pipeline(self, pipeline):
-        """0 / "mega" = megakernel (default), 1 / "wavefront" = shading + lean traversal kernels"""
-        v = {"mega": 0, "megakernel": 0, "wavefront": 1}.get(pipeline, pipeline)
-        self._chk(self.lib.prt_set_pipeline(self.ctx, int(v)), "prt_set_pipeline")
+    def set_walk_min_lanes(self, lanes):
+        self._chk(self.lib.prt_set_walk_min_lanes(self.ctx, int(lanes)), "prt_set_walk_min_lanes")
 
     def synchronize(self):
         self._chk(self.lib.prt_synchronize(self.ctx), "prt_synchronize")

@@ -15,6 +15,7 @@
 #include "prt.h"
 #include "pt_launch.h"
 #include "pt_layout.h"
+#include "pt_pack.h"
 
 using namespace prt;
 
@@ -51,10 +52,7 @@ struct prt_ctx {
     hipEvent_t sub_ev0[MAX_SUB][2] = {};          // its start (prt_render_spp times every launch)
     hipEvent_t fork_ev = nullptr;
     unsigned long long* h_unfinished = nullptr;   // pinned, [MAX_SUB][2]: written by the last wave of a launch
-    // wavefront pipeline (optional)
-    int pipeline = 0;                              // 0 = megakernel, 1 = wavefront
-    DevWave wv{};
-    bool wv_allocated = false;
+    uint32_t walk_min_lanes = 8;                   // FrameArgs::walk_min_lanes (prt_set_walk_min_lanes, PRT_WALK_MIN_LANES)
     prt_stats stats{};
     std::string err;
     const char* variant = "";
@@ -114,7 +112,7 @@ extern "C" int prt_create(int device, const prt_config* cfg, prt_ctx** out) {
             return PRT_ERR_HIP;
         }
     c->stream = c->own_stream;
-    if (const char* e = std::getenv("PRT_PIPELINE")) c->pipeline = (std::strcmp(e, "wavefront") == 0 || std::strcmp(e, "1") == 0) ? 1 : 0;
+    if (const char* ev = std::getenv("PRT_WALK_MIN_LANES")) { const int k = std::atoi(ev); if (k >= 1 && k <= 64) c->walk_min_lanes = (uint32_t)k; }
     *out = c;
     return PRT_OK;
 }
@@ -128,32 +126,6 @@ static void free_frame(prt_ctx* c) {
     p = c->S.q4; free_dev(p); c->S.q4 = nullptr;
     p = c->fb; free_dev(p); c->fb = nullptr;
 }
-static void free_wave(prt_ctx* c) {
-    void* p;
-    p = c->wv.hc0; free_dev(p); p = c->wv.hc1; free_dev(p); p = c->wv.prog; free_dev(p); p = c->wv.ctx; free_dev(p);
-    p = c->wv.ray_o; free_dev(p); p = c->wv.ray_d; free_dev(p); p = c->wv.res0; free_dev(p); p = c->wv.res1; free_dev(p);
-    p = c->wv.qcount; free_dev(p);
-    c->wv = DevWave{};
-    c->wv_allocated = false;
-}
-static int alloc_wave(prt_ctx* c) {
-    if (c->wv_allocated) return PRT_OK;
-    const size_t n = c->npix;
-    DevWave& w = c->wv;
-    w.npix = n;
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&w.hc0), n * 16));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&w.hc1), n * 16));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&w.prog), n * 16));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&w.ctx), n * 16 * PRT_WF_CTX_PLANES));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&w.ray_o), n * 16));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&w.ray_d), n * 16));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&w.res0), n * 16));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&w.res1), n * 4));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&w.qcount), 2 * sizeof(unsigned)));
-    c->wv_allocated = true;
-    return PRT_OK;
-}
-
 static void free_scene(prt_ctx* c) {
     free_dev(c->d_pairs); free_dev(c->d_tri_geom); free_dev(c->d_tri_nrm);
     free_dev(c->d_spheres); free_dev(c->d_quads); free_dev(c->d_sdfs); free_dev(c->d_mats);
@@ -173,7 +145,6 @@ extern "C" void prt_destroy(prt_ctx* c) {
     if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
     if (c->h_unfinished) (void)hipHostFree(c->h_unfinished);
     free_frame(c);
-    free_wave(c);
     free_scene(c);
     free_dev(c->d_env);
     void* p = c->d_seeds; free_dev(p);
@@ -193,214 +164,40 @@ static int upload(prt_ctx* c, void*& dst, const std::vector<T>& src) {
     return PRT_OK;
 }
 
-static DevMaterial pack_material(const prt_material& m) {
-    DevMaterial d;
-    std::memset(&d, 0, sizeof(d));
-    for (int i = 0; i < 3; ++i) { d.color[i] = m.color[i]; d.eta[i] = m.eta[i]; d.k[i] = m.k[i]; }
-    d.roughness = m.roughness;
-    d.bits = (uint32_t)m.t | ((uint32_t)m.lobes << 16) | ((uint32_t)m.dist << 24);
-    return d;
-}
-
 extern "C" int prt_upload_scene(prt_ctx* c, const prt_scene_desc* s) {
     CTX_CHECK(c);
-    if (!s) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: null scene");
+    // everything that can be refused is refused before the old scene is touched (pt_pack.cpp: pure host code)
+    PackedScene ps;
+    std::string perr;
+    int rc = pack_scene(c->cfg, s, ps, perr);
+    if (rc) return fail(c, rc, perr);
     HIPCHK(c, hipSetDevice(c->device));
-    const uint32_t n_sph = s->object_count[0], n_sdf = s->object_count[1], n_box = s->object_count[2], n_quad = s->object_count[3];
-    const uint32_t n_mesh = s->object_count[7];
-    if (n_box) return fail(c, PRT_ERR_UNSUPPORTED, "prt_upload_scene: box primitives never render in the reference (box.cl is dead code)");
-    if (n_sph + n_sdf + n_quad != n_mesh) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: object_count does not add up");
-    if (n_sdf && !(c->cfg.geom_flags & PRT_GEOM_SDF)) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: SDF meshes but the config has no H_SDF");
-    if (n_mesh && !s->meshes) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: meshes is null");
-    const uint32_t T = s->triangle_count, N = s->bvh_node_count;
-    if (T && (!s->vertices || !s->normals || !s->primitive_indices || !s->bvh_nodes || !N))
-        return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: triangle buffers incomplete");
-
-    // ---- primitives + materials
-    std::vector<DevSphere> spheres(n_sph);
-    std::vector<DevQuad> quads(n_quad);
-    std::vector<DevSdf> sdfs(n_sdf);
-    std::vector<DevMaterial> mats(n_mesh + 2);
-    std::memset(mats.data(), 0, mats.size() * sizeof(DevMaterial));
-    for (uint32_t i = 0; i < n_mesh; ++i) {
-        const prt_mesh& m = s->meshes[i];
-        mats[1 + i] = pack_material(m.mat);
-        if (i < n_sph) {
-            if (!(m.t & PRT_GEOM_SPHERE)) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: mesh order/type mismatch (sphere expected)");
-            DevSphere& d = spheres[i];
-            d.pos[0] = m.pos[0]; d.pos[1] = m.pos[1]; d.pos[2] = m.pos[2]; d.radius = m.joker[0];
-        } else if (i < n_sph + n_sdf) {
-            if (!(m.t & PRT_GEOM_SDF)) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: mesh order/type mismatch (sdf expected)");
-            DevSdf& d = sdfs[i - n_sph];
-            d.pos[0] = m.pos[0]; d.pos[1] = m.pos[1]; d.pos[2] = m.pos[2]; d.type = m.t;
-            for (int k = 0; k < 4; ++k) d.params[k] = m.joker[k];
-        } else {
-            if (!(m.t & PRT_GEOM_QUAD)) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: mesh order/type mismatch (quad expected)");
-            DevQuad& d = quads[i - n_sph - n_sdf];
-            std::memset(&d, 0, sizeof(d));
-            for (int k = 0; k < 3; ++k) { d.base[k] = m.joker[k]; d.edge0[k] = m.joker[3 + k]; d.edge1[k] = m.joker[6 + k]; d.normal[k] = m.joker[9 + k]; }
-            d.area = m.joker[12];
-            // kernels/geometry/quad.cl:16 anchor = base - (edge0 + edge1) * 0.5f ; :26-27 dot(edge, edge)
-            for (int k = 0; k < 3; ++k) d.anchor[k] = d.base[k] - (d.edge0[k] + d.edge1[k]) * 0.5f;
-            d.e0e0 = d.edge0[0] * d.edge0[0] + d.edge0[1] * d.edge0[1] + d.edge0[2] * d.edge0[2];
-            d.e1e1 = d.edge1[0] * d.edge1[0] + d.edge1[1] * d.edge1[1] + d.edge1[2] * d.edge1[2];
-            // pt_device.h out_of_unit_range: half an ulp of 1.0 scaled by the divisor, NaN = "divide instead"
-            auto half_ulp = [](float c) { return (c >= 9.094947017729282e-13f && c <= 1099511627776.0f) ? c * 5.9604644775390625e-08f : std::nanf(""); };
-            d.u0 = half_ulp(d.e0e0); d.u1 = half_ulp(d.e1e1);
-        }
-    }
-    if (s->obj_material) mats[n_mesh + 1] = pack_material(*s->obj_material);
-
-    // ---- BVH: reference layout -> NodePair records (inner nodes only), DFS order
-    std::vector<NodePair> pairs;
-    DevScene sc{};
-    sc.root_is_leaf = 1;
-    sc.stack_levels = 1;
-    if (T) {
-        const prt_bvh_node* nodes = s->bvh_nodes;
-        auto leaf_ok = [&](const prt_bvh_node& nd) { return (uint64_t)nd.first_child_or_primitive + nd.primitive_count <= T; };
-        if (nodes[0].is_leaf) {
-            if (!leaf_ok(nodes[0])) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: root leaf range out of bounds");
-            sc.root_leaf_first = nodes[0].first_child_or_primitive;
-            sc.root_leaf_count = nodes[0].primitive_count;
-        } else {
-            sc.root_is_leaf = 0;
-            std::vector<uint32_t> pair_of(N, 0xFFFFFFFFu);
-            // Order of the NodePair records in memory.  Breadth-first keeps the top of the tree (which every ray
-            // walks) contiguous; depth-first (pre-order, left child right behind its parent) gives deep walks through
-            // big trees better line / page locality.  PRT_PAIR_ORDER=bfs|dfs overrides the choice.
-            std::vector<uint32_t> order;
-            const char* e_order = std::getenv("PRT_PAIR_ORDER");
-            const bool dfs = e_order ? (std::strcmp(e_order, "dfs") == 0) : (N > 65536u);
-            order.reserve(N / 2 + 1);
-            if (!dfs) {
-                order.push_back(0);
-                pair_of[0] = 0;
-                for (size_t head = 0; head < order.size(); ++head) {
-                    const uint32_t n = order[head];
-                    const uint32_t fc = nodes[n].first_child_or_primitive;
-                    if ((uint64_t)fc + 1 >= N) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: BVH child index out of range");
-                    for (uint32_t ch = fc; ch <= fc + 1; ++ch) {
-                        if (nodes[ch].is_leaf) continue;
-                        if (pair_of[ch] != 0xFFFFFFFFu || order.size() >= N) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: BVH is not a tree");
-                        pair_of[ch] = (uint32_t)order.size();
-                        order.push_back(ch);
-                    }
-                }
-            } else {
-                std::vector<uint32_t> st{0};
-                while (!st.empty()) {
-                    const uint32_t n = st.back();
-                    st.pop_back();
-                    if (n >= N || pair_of[n] != 0xFFFFFFFFu || order.size() >= N) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: BVH is not a tree");
-                    pair_of[n] = (uint32_t)order.size();
-                    order.push_back(n);
-                    const uint32_t fc = nodes[n].first_child_or_primitive;
-                    if ((uint64_t)fc + 1 >= N) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: BVH child index out of range");
-                    if (!nodes[fc + 1].is_leaf) st.push_back(fc + 1);
-                    if (!nodes[fc].is_leaf) st.push_back(fc);
-                }
-            }
-            pairs.resize(order.size());
-            for (size_t k = 0; k < order.size(); ++k) {
-                const prt_bvh_node& nd = nodes[order[k]];
-                NodePair& p = pairs[k];
-                for (int ch = 0; ch < 2; ++ch) {
-                    const prt_bvh_node& cn = nodes[nd.first_child_or_primitive + ch];
-                    for (int j = 0; j < 6; ++j) p.b[6 * ch + j] = cn.bounds[j];
-                    if (cn.is_leaf) {
-                        if (!leaf_ok(cn)) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: leaf range out of bounds");
-                        if (cn.primitive_count == 0xFFFFFFFFu) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: bad leaf");
-                        p.meta[2 * ch] = cn.first_child_or_primitive;
-                        p.meta[2 * ch + 1] = cn.primitive_count;
-                    } else {
-                        p.meta[2 * ch] = pair_of[nd.first_child_or_primitive + ch];
-                        p.meta[2 * ch + 1] = 0xFFFFFFFFu;
-                    }
-                }
-            }
-            // Most entries a walk can hold: one push per pair with two inner children on the way down.
-            // The reference's stack has 64 entries (bvh.cl:131) and overflows silently beyond that.
-            uint32_t max_sp = 0;
-            std::vector<std::pair<uint32_t, uint32_t>> todo{{0u, 0u}};
-            while (!todo.empty()) {
-                const std::pair<uint32_t, uint32_t> it = todo.back();
-                todo.pop_back();
-                const NodePair& p = pairs[it.first];
-                const bool in0 = p.meta[1] == 0xFFFFFFFFu, in1 = p.meta[3] == 0xFFFFFFFFu;
-                const uint32_t sp = it.second + ((in0 && in1) ? 1u : 0u);
-                if (sp > max_sp) max_sp = sp;
-                if (in0) todo.push_back({p.meta[0], sp});
-                if (in1) todo.push_back({p.meta[2], sp});
-            }
-            if (max_sp > 64u) return fail(c, PRT_ERR_UNSUPPORTED, "prt_upload_scene: BVH needs more than the 64 traversal-stack entries of the reference (bvh.cl:131)");
-            sc.stack_levels = max_sp + 1;
-        }
-    } else {
-        sc.root_leaf_first = 0; sc.root_leaf_count = 0;        // "no OBJ" = empty leaf root
-    }
-    // ---- triangles in leaf-slot order
-    std::vector<TriGeom> tg(T);
-    std::vector<TriNrm> tn(T);
-    for (uint32_t i = 0; i < T; ++i) {
-        const uint32_t fv = (uint32_t)s->primitive_indices[i] * 3u;        // triangle.cl:7 (uint arithmetic)
-        if ((uint64_t)fv + 2 >= (uint64_t)T * 3) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: primitive index out of range");
-        const float* p0 = s->vertices + 4 * (size_t)fv;
-        const float* p1 = p0 + 4; const float* p2 = p0 + 8;
-        TriGeom& g = tg[i];
-        float e1[3], e2[3];
-        for (int k = 0; k < 3; ++k) { g.p0[k] = p0[k]; e1[k] = p0[k] - p1[k]; e2[k] = p2[k] - p0[k]; }   // triangle.cl:12-13
-        for (int k = 0; k < 3; ++k) { g.e1[k] = e1[k]; g.e2[k] = e2[k]; }
-        g.n[0] = e1[1] * e2[2] - e1[2] * e2[1];                                                       // triangle.cl:15
-        g.n[1] = e1[2] * e2[0] - e1[0] * e2[2];
-        g.n[2] = e1[0] * e2[1] - e1[1] * e2[0];
-        const float* n0 = s->normals + 4 * (size_t)fv;
-        for (int k = 0; k < 3; ++k) { tn[i].n0[k] = n0[k]; tn[i].n1[k] = n0[4 + k]; tn[i].n2[k] = n0[8 + k]; }
-        tn[i].n0[3] = tn[i].n1[3] = tn[i].n2[3] = 0.0f;
-    }
-
     (void)hipStreamSynchronize(c->stream);
-    int rc;
-    if ((rc = upload(c, c->d_pairs, pairs)) || (rc = upload(c, c->d_tri_geom, tg)) || (rc = upload(c, c->d_tri_nrm, tn)) ||
-        (rc = upload(c, c->d_spheres, spheres)) || (rc = upload(c, c->d_quads, quads)) || (rc = upload(c, c->d_sdfs, sdfs)) ||
-        (rc = upload(c, c->d_mats, mats)))
+    // from here on the old buffers are being replaced: the context has no scene until every upload has succeeded
+    c->have_scene = false;
+    const float* env = c->sc.env; const int env_w = c->sc.env_w, env_h = c->sc.env_h;    // the environment map survives scene uploads
+    c->sc = DevScene{};
+    c->sc.env = env; c->sc.env_w = env_w; c->sc.env_h = env_h;
+    if ((rc = upload(c, c->d_pairs, ps.pairs)) || (rc = upload(c, c->d_tri_geom, ps.tg)) || (rc = upload(c, c->d_tri_nrm, ps.tn)) ||
+        (rc = upload(c, c->d_spheres, ps.spheres)) || (rc = upload(c, c->d_quads, ps.quads)) || (rc = upload(c, c->d_sdfs, ps.sdfs)) ||
+        (rc = upload(c, c->d_mats, ps.mats)))
         return rc;
-
+    DevScene sc = ps.sc;
     sc.pairs = static_cast<const NodePair*>(c->d_pairs);
-    sc.n_pairs = (uint32_t)pairs.size();
     sc.tri_geom = static_cast<const TriGeom*>(c->d_tri_geom);
     sc.tri_nrm = static_cast<const TriNrm*>(c->d_tri_nrm);
     sc.spheres = static_cast<const DevSphere*>(c->d_spheres);
     sc.quads = static_cast<const DevQuad*>(c->d_quads);
     sc.sdfs = static_cast<const DevSdf*>(c->d_sdfs);
     sc.mats = static_cast<const DevMaterial*>(c->d_mats);
-    sc.n_spheres = n_sph; sc.n_quads = n_quad; sc.quad_mesh_base = n_sph + n_sdf; sc.n_meshes = n_mesh; sc.n_sdfs = n_sdf;
-    sc.marching_steps = c->cfg.marching_steps; sc.shadow_marching_steps = c->cfg.shadow_marching_steps;
-    sc.light_sphere = sc.light_quad = 0xFFFFFFFFu; sc.light_mesh = 0;
-    const prt_config& cfg = c->cfg;
-    if (cfg.light_count) {
-        const uint32_t li = cfg.light_indices[0];
-        if (li >= n_mesh) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: light index out of range");
-        sc.light_mesh = li;
-        if (li < n_sph) sc.light_sphere = li;
-        else if (li >= n_sph + n_sdf) sc.light_quad = li - n_sph - n_sdf;
-        // an SDF light cannot be sampled (kernels/geometry/geometry.cl:11-32 returns false): both stay unset
-    }
-    sc.active_mats = cfg.active_mats; sc.geom_flags = cfg.geom_flags;
-    sc.max_bounces = cfg.max_bounces; sc.max_diff_bounces = cfg.max_diff_bounces; sc.max_spec_bounces = cfg.max_spec_bounces;
-    sc.max_trans_bounces = cfg.max_trans_bounces; sc.max_scattering_events = cfg.max_scattering_events;
-    sc.has_medium = cfg.has_global_medium; sc.fog_abs_only = cfg.fog_abs_only; sc.alpha_testing = cfg.alpha_testing;
-    sc.phase_function = cfg.phase_function; sc.fog_sigma_s = cfg.fog_sigma_s; sc.fog_sigma_t = cfg.fog_sigma_t; sc.phase_g = cfg.phase_g;
-    sc.ntrans_mask = cfg.active_mats & (PRT_MAT_DIEL | PRT_MAT_ROUGH_DIEL);
-    // keep the environment map across scene uploads
-    sc.env = c->sc.env; sc.env_w = c->sc.env_w; sc.env_h = c->sc.env_h;
+    sc.env = env; sc.env_w = env_w; sc.env_h = env_h;
     c->sc = sc;
-    c->have_scene = true;
     if (!c->sc.env) {
         const float black[3] = {0.f, 0.f, 0.f};
         rc = prt_upload_envmap(c, black, 1, 1);
         if (rc) return rc;
     }
+    c->have_scene = true;
     return PRT_OK;
 }
 
@@ -450,16 +247,24 @@ extern "C" int prt_set_row_blocks(prt_ctx* c, int width, int full_height, int bl
 static int alloc_frame(prt_ctx* c, int width, int full_height, int row0, int rows) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    // the context has no frame until every plane of the new one exists: a failed (re)allocation must leave it NOT READY,
+    // never "ready" with null planes
+    c->have_size = false;
     free_frame(c);
-    free_wave(c);
+    c->npix = 0;
+    const size_t npix = (size_t)width * (size_t)rows;
+    hipError_t e = hipSuccess;
+    void** planes[6] = {reinterpret_cast<void**>(&c->S.q0), reinterpret_cast<void**>(&c->S.q1), reinterpret_cast<void**>(&c->S.q2),
+                        reinterpret_cast<void**>(&c->S.q3), reinterpret_cast<void**>(&c->S.q4), reinterpret_cast<void**>(&c->fb)};
+    for (int k = 0; k < 6 && e == hipSuccess; ++k) e = hipMalloc(planes[k], npix * 16);
+    if (e != hipSuccess) {
+        free_frame(c);
+        (void)hipGetLastError();
+        c->err = std::string("prt frame allocation (") + std::to_string(width) + " x " + std::to_string(rows) + "): " + hipGetErrorString(e);
+        return PRT_ERR_HIP;
+    }
     c->width = width; c->full_height = full_height; c->row0 = row0; c->rows = rows;
-    c->npix = (size_t)width * (size_t)rows;
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->S.q0), c->npix * 16));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->S.q1), c->npix * 16));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->S.q2), c->npix * 16));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->S.q3), c->npix * 16));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->S.q4), c->npix * 16));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->fb), c->npix * 16));
+    c->npix = npix;
     c->have_size = true;
     return prt_reset(c);
 }
@@ -516,6 +321,7 @@ static FrameArgs frame_args(prt_ctx* c, uint32_t first_frame, uint32_t n, const 
     fa.unfinished = count ? c->d_counters : nullptr;
     fa.unfinished_host = nullptr;
     fa.tile_first = 0; fa.tile_stride = 1;
+    fa.walk_min_lanes = c->walk_min_lanes;
     return fa;
 }
 
@@ -536,40 +342,6 @@ static int join_streams(prt_ctx* c, int K) {
     return PRT_OK;
 }
 
-// Wavefront pipeline: passes of (shade, traverse) until every pixel has done its n_frames segments (or froze).
-static int render_wavefront(prt_ctx* c, uint32_t first_frame, uint32_t n_frames, uint32_t spp, uint32_t* frames_used) {
-    int rc = alloc_wave(c);
-    if (rc) return rc;
-    const DevWave& w = c->wv;
-    // every pixel starts the call at a segment boundary with an empty hit cache
-    HIPCHK(c, hipMemsetAsync(w.prog, 0, c->npix * 16, c->stream));
-    HIPCHK(c, hipMemsetAsync(w.hc1, 0, c->npix * 16, c->stream));
-    HIPCHK(c, hipMemsetAsync(w.qcount, 0, 2 * sizeof(unsigned), c->stream));
-    const unsigned trav_blocks = 2048;                      // 256 CUs x 8 workgroups of 4 waves = 8 waves/SIMD, grid-stride
-    const unsigned batch = 16;
-    const unsigned long long max_passes = 4ull * n_frames + 8;
-    unsigned long long unfinished = 1, pass = 0;
-    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    while (unfinished && pass < max_passes) {
-        for (unsigned b = 0; b < batch; ++b, ++pass) {
-            const bool last = (b + 1 == batch);
-            if (last) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, sizeof(unsigned long long), c->stream));
-            FrameArgs fa = frame_args(c, first_frame, n_frames, c->d_seeds, spp, last);
-            launch_wf_pass(c->sc, c->cam, c->S, w, fa, c->fb, (unsigned)pass, trav_blocks, c->stream);
-            c->stats.launches += 2;
-        }
-        HIPCHK(c, hipMemcpyAsync(&unfinished, c->d_counters, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-    }
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-    c->timing_pending = true;
-    c->variant = "wavefront";
-    if (frames_used) *frames_used = (uint32_t)pass;
-    if (unfinished) return fail(c, PRT_ERR_NOT_READY, "wavefront: pass limit reached before every pixel finished");
-    return PRT_OK;
-}
-
 extern "C" int prt_render_frames(prt_ctx* c, uint32_t first_frame, uint32_t n_frames, const int32_t* seed_pairs) {
     CTX_CHECK(c);
     int rc = ready(c, "prt_render_frames");
@@ -579,11 +351,6 @@ extern "C" int prt_render_frames(prt_ctx* c, uint32_t first_frame, uint32_t n_fr
     c->stats.launches = 0; c->stats.frames = 0; c->stats.kernel_ms = 0.0; c->stats.kernel_sum_ms = 0.0; c->stats.concurrent = 1;
     if (!n_frames) return PRT_OK;
     if ((rc = ensure_seeds(c, seed_pairs, n_frames))) return rc;
-    if (c->pipeline == 1) {
-        rc = render_wavefront(c, first_frame, n_frames, 0, nullptr);
-        c->stats.frames = n_frames;
-        return rc;
-    }
     const unsigned step = frames_per_launch();
     const int K = sub_parts(c);
     c->stats.concurrent = (uint32_t)K;
@@ -614,11 +381,6 @@ extern "C" int prt_render_spp(prt_ctx* c, uint32_t spp, uint32_t max_frames, con
     HIPCHK(c, hipSetDevice(c->device));
     c->stats.launches = 0; c->stats.frames = 0; c->stats.kernel_ms = 0.0; c->stats.kernel_sum_ms = 0.0; c->stats.concurrent = 1;
     if ((rc = ensure_seeds(c, seed_pairs, max_frames))) return rc;
-    if (c->pipeline == 1) {
-        rc = render_wavefront(c, 1, max_frames, spp, frames_used);
-        c->stats.frames = max_frames;
-        return rc;
-    }
     const unsigned step = frames_per_launch();
     const int K = sub_parts(c);
     c->stats.concurrent = (uint32_t)K;
@@ -641,7 +403,20 @@ extern "C" int prt_render_spp(prt_ctx* c, uint32_t spp, uint32_t max_frames, con
         // or fill kernel between launches (with the other stream's kernel filling the chip those waited ~1.7 ms for a
         // wave slot) and the HIP events around a launch time the kernel alone.  A launch queued behind one that
         // reported 0 (PRT_QUEUE_DEPTH=2) finds every pixel frozen and returns at once.
+        // the sub-part counters are {unfinished, waves done}; a launch that ended abnormally in an earlier call would
+        // have left them non-zero and every later ticket wrong: start from zero, ordered before the fork
+        HIPCHK(c, hipMemsetAsync(c->d_counters + 4, 0, 2 * prt_ctx::MAX_SUB * sizeof(unsigned long long), c->stream));
         if ((rc = fork_streams(c, K))) return rc;
+        // any failure below leaves through abort_streams: kernels may still be running on the internal streams, the
+        // caller's stream must not run ahead of them and the context must stay usable
+        auto abort_streams = [&](int code, const std::string& msg) {
+            for (int j = 0; j < K; ++j) (void)hipStreamSynchronize(c->sub_stream[j]);
+            (void)hipMemsetAsync(c->d_counters + 4, 0, 2 * prt_ctx::MAX_SUB * sizeof(unsigned long long), c->stream);
+            (void)hipStreamSynchronize(c->stream);
+            (void)hipGetLastError();
+            return fail(c, code, msg);
+        };
+#define SUBCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return abort_streams(PRT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
         uint32_t fj[prt_ctx::MAX_SUB] = {0, 0, 0, 0};            // frames queued so far
         uint32_t f_end[prt_ctx::MAX_SUB][2] = {};                 // ... up to the end of the launch in each slot
         unsigned issued[prt_ctx::MAX_SUB] = {0, 0, 0, 0}, retired[prt_ctx::MAX_SUB] = {0, 0, 0, 0};
@@ -663,9 +438,9 @@ extern "C" int prt_render_spp(prt_ctx* c, uint32_t spp, uint32_t max_frames, con
                     fa.unfinished_host = c->h_unfinished + 2 * j + slot;
                     fa.tile_first = (uint32_t)j; fa.tile_stride = (uint32_t)K;
                     c->h_unfinished[2 * j + slot] = ~0ull;
-                    HIPCHK(c, hipEventRecord(c->sub_ev0[j][slot], c->sub_stream[j]));
+                    SUBCHK(hipEventRecord(c->sub_ev0[j][slot], c->sub_stream[j]));
                     c->variant = launch_render(c->sc, c->cam, c->S, fa, c->fb, c->sub_stream[j]);
-                    HIPCHK(c, hipEventRecord(c->sub_ev[j][slot], c->sub_stream[j]));
+                    SUBCHK(hipEventRecord(c->sub_ev[j][slot], c->sub_stream[j]));
                     ++c->stats.launches;
                     fj[j] += n;
                     f_end[j][slot] = fj[j];
@@ -677,11 +452,11 @@ extern "C" int prt_render_spp(prt_ctx* c, uint32_t spp, uint32_t max_frames, con
                     const unsigned slot = retired[j] & 1u;
                     const hipError_t q = hipEventQuery(c->sub_ev[j][slot]);
                     if (q == hipErrorNotReady) continue;
-                    HIPCHK(c, q);
+                    SUBCHK(q);
                     float ms = 0.f;
                     if (hipEventElapsedTime(&ms, c->sub_ev0[j][slot], c->sub_ev[j][slot]) == hipSuccess) c->stats.kernel_sum_ms += ms;
                     const unsigned long long left = __atomic_load_n(c->h_unfinished + 2 * j + slot, __ATOMIC_ACQUIRE);
-                    if (left == ~0ull) return fail(c, PRT_ERR_HIP, "prt_render_spp: a launch ended without reporting its unfinished pixels");
+                    if (left == ~0ull) return abort_streams(PRT_ERR_HIP, "prt_render_spp: a launch ended without reporting its unfinished pixels");
                     ++retired[j];
                     progressed = true;
                     if (!stop[j]) {
@@ -693,6 +468,7 @@ extern "C" int prt_render_spp(prt_ctx* c, uint32_t spp, uint32_t max_frames, con
             if (!busy && !progressed) break;
             if (!progressed) std::this_thread::sleep_for(std::chrono::microseconds(50));
         }
+#undef SUBCHK
         for (int j = 0; j < K; ++j) fj[j] = f_done[j];
         for (int j = 0; j < K; ++j) f = fj[j] > f ? fj[j] : f;
         unfinished = exhausted ? 1 : 0;
@@ -708,10 +484,10 @@ extern "C" int prt_render_spp(prt_ctx* c, uint32_t spp, uint32_t max_frames, con
     return PRT_OK;
 }
 
-extern "C" int prt_set_pipeline(prt_ctx* c, int pipeline) {
+extern "C" int prt_set_walk_min_lanes(prt_ctx* c, uint32_t lanes) {
     CTX_CHECK(c);
-    if (pipeline != 0 && pipeline != 1) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_set_pipeline: 0 = megakernel, 1 = wavefront");
-    c->pipeline = pipeline;
+    if (lanes < 1 || lanes > 64) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_set_walk_min_lanes: 1..64");
+    c->walk_min_lanes = lanes;
     return PRT_OK;
 }
 

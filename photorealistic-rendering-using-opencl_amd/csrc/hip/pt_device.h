@@ -30,7 +30,11 @@ namespace dev {
 #define PT_INV_TWO_PI 0.1591549430918953357688837633725f
 #define PT_INV_FOUR_PI 0.0795774715459476678844418816863f
 
+#ifdef PT_EMU                                            // tests/emu: the same functions compiled for the host (checker of the
+#define PT_DEV __host__ __device__ __forceinline__      // lane machine's schedule independence), never part of libprt
+#else
 #define PT_DEV __device__ __forceinline__
+#endif
 #define PT_HD __host__ __device__ __forceinline__      // the few helpers the host shares (camera basis)
 
 struct f3 { float x, y, z; };
@@ -62,12 +66,14 @@ PT_DEV float avg3(f3 v) { return (v.x * 1.0f + v.y * 1.0f + v.z * 1.0f) * 0.3333
 #define PT_RECIP_STEPS 1
 #endif
 PT_DEV float hw_recip(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
     const unsigned e = (prt_f2u(x) >> 23) & 0xffu;
     if (e - 2u < 251u) {                                        // 2^-125 <= |x| < 2^126
         float r = __builtin_amdgcn_rcpf(x);
         for (int k = 0; k < PT_RECIP_STEPS; ++k) r = __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
         return r;
     }
+#endif
     return 1.0f / x;
 }
 PT_DEV float hw_min(float a, float b) { return __builtin_fminf(a, b); }
@@ -270,87 +276,81 @@ PT_DEV PairTest test_pair(const PairData& d, const RayPre& p, float best_t) {
     return r;
 }
 
-struct TravReq { bool want; f3 o, d; float tmax; };
 struct TravRes { bool found; float t; TriHit th; };
 
-// bvh.cl:132-206 (closest hit) / :43-114 (any hit): returns true if (closest) a triangle was accepted,
-// (any) a triangle closer than rq.tmax exists.
-PT_DEV TravRes walk(const DevScene& sc, const bool ANY_HIT, const TravReq& rq, const TravStack& stack) {
-    TravRes res;
-    res.found = false; res.t = rq.tmax;
-    res.th.u = res.th.v = res.th.w = 0.0f; res.th.slot = 0;
-    Ray ray;
-    ray.origin = rq.o; ray.dir = rq.d;
+// bvh.cl:132-206 (closest hit) / :43-114 (any hit), as a RESUMABLE walk: walk_begin = set-up + the step at the root,
+// walk_step = one step of bvh.cl:144-196 (closest hit) / :54-104 (any hit).  Same visiting order as the reference:
+// both children's boxes are tested against the CURRENT best t before either leaf is tested; leaf children are tested
+// immediately, left first; of two inner children the nearer (by entry distance, ties -> left) is followed and the
+// other pushed.  Real branches (scalar mask work, free next to the vector pipe) rather than selects: the shape with
+// the fewest vector instructions per step.  The lane machine (lane_kernel) runs a wave's walks for a bounded number of
+// steps; a lane whose ray needs more keeps {node, sp, t, hit} for the wave's next walk phase, the LDS stack column
+// stays the lane's own.  found: (closest) a triangle was accepted, (any) a triangle closer than tmax exists.
+struct WalkState { unsigned node, sp; float t; TriHit th; bool found, done; };
+
+PT_DEV void walk_begin(const DevScene& sc, const bool ANY_HIT, const Ray& ray, const float tmax, const RayPre& p, WalkState& w,
+                       const TravStack& stack) {
+    w.found = false; w.done = false; w.t = tmax;
+    w.th.u = w.th.v = w.th.w = 0.0f; w.th.slot = 0;
+    w.node = 0; w.sp = 0;
     if (sc.root_is_leaf) {                                       // tiny meshes: no tree to walk
         for (unsigned i = sc.root_leaf_first; i < sc.root_leaf_first + sc.root_leaf_count; ++i)
-            if (hit_triangle(sc.tri_geom, i, ray, res.t, res.th)) { res.found = true; if (ANY_HIT) return res; }
-        return res;
+            if (hit_triangle(sc.tri_geom, i, ray, w.t, w.th)) { w.found = true; if (ANY_HIT) break; }
+        w.done = true;
+        return;
     }
-    const RayPre p = ray_pre(ray);
-    // One iteration = one step of bvh.cl:144-196 (closest hit) / :54-104 (any hit).  Same visiting
-    // order as the reference: both children's boxes are tested against the CURRENT best_t before
-    // either leaf is tested; leaf children are tested immediately, left first; of two inner children
-    // the nearer (by entry distance, ties -> left) is followed and the other pushed.  The kernel is
-    // bound by vector-ALU issue and most steps run for the one or two lanes of a wave that are still
-    // walking, so the shape below is the one with the fewest vector instructions per step: real
-    // branches (scalar mask work, free next to the vector pipe) rather than selects.
-    unsigned node = 0;
-    unsigned sp = 0;
-    {
-        // The step at the root, which every lane of the wave takes, reads its node through the scalar cache (the address
-        // is uniform): no vector-memory instruction, and the 6 rays in 10 that miss both of the root's children never
-        // issue one in this walk.  (All 64 lanes fetching one 64 B node is the heaviest load the texture-data path sees:
-        // it is 60 % busy in this kernel.)  A root with a leaf child that is hit takes the general loop from node 0.
-        const PairData d = load_pair(sc.pairs, 0u);
-        const PairTest pt = test_pair(d, p, res.t);
-        const uint4 meta = d.meta;
-        if (!((pt.go0 & (meta.y != 0xFFFFFFFFu)) | (pt.go1 & (meta.w != 0xFFFFFFFFu)))) {
-            if (pt.go0 != pt.go1) {
-                node = pt.go0 ? meta.x : meta.z;
-            } else if (pt.go0) {
-                unsigned nearc = meta.x, farc = meta.z;
-                if (pt.entry0 > pt.entry1) { nearc = meta.z; farc = meta.x; }
-                stack.lds[0] = farc;
-                sp = 1;
-                node = nearc;
-            } else {
-                return res;                                      // missed both: the stack is empty, the walk is over
-            }
-        }
-    }
-    for (;;) {
-        const PairData d = load_pair(sc.pairs, node);
-        const PairTest pt = test_pair(d, p, res.t);
-        const uint4 meta = d.meta;
-        bool go0 = pt.go0, go1 = pt.go1;
-        const bool hit_leaf0 = go0 & (meta.y != 0xFFFFFFFFu), hit_leaf1 = go1 & (meta.w != 0xFFFFFFFFu);
-        if (hit_leaf0 | hit_leaf1) {                             // one region: a step through two inner children skips it in one branch
-            if (hit_leaf0) {                                     // left child is a leaf
-                for (unsigned i = meta.x; i < meta.x + meta.y; ++i)
-                    if (hit_triangle(sc.tri_geom, i, ray, res.t, res.th)) { res.found = true; if (ANY_HIT) return res; }
-                go0 = false;
-            }
-            if (hit_leaf1) {
-                for (unsigned i = meta.z; i < meta.z + meta.w; ++i)
-                    if (hit_triangle(sc.tri_geom, i, ray, res.t, res.th)) { res.found = true; if (ANY_HIT) return res; }
-                go1 = false;
-            }
-        }
-        if (go0 != go1) {
-            node = go0 ? meta.x : meta.z;
-        } else if (go0) {
+    // The step at the root, which every lane of the wave takes, reads its node through the scalar cache (the address is
+    // uniform): no vector-memory instruction, and the 6 rays in 10 that miss both of the root's children never issue one
+    // in this walk.  A root with a leaf child that is hit takes the general step from node 0.
+    const PairData d = load_pair(sc.pairs, 0u);
+    const PairTest pt = test_pair(d, p, w.t);
+    const uint4 meta = d.meta;
+    if (!((pt.go0 & (meta.y != 0xFFFFFFFFu)) | (pt.go1 & (meta.w != 0xFFFFFFFFu)))) {
+        if (pt.go0 != pt.go1) {
+            w.node = pt.go0 ? meta.x : meta.z;
+        } else if (pt.go0) {
             unsigned nearc = meta.x, farc = meta.z;
             if (pt.entry0 > pt.entry1) { nearc = meta.z; farc = meta.x; }
-            stack.lds[sp * stack.stride] = farc;
-            ++sp;
-            node = nearc;
+            stack.lds[0] = farc;
+            w.sp = 1;
+            w.node = nearc;
         } else {
-            if (sp == 0u) break;
-            --sp;
-            node = stack.lds[sp * stack.stride];
+            w.done = true;                                       // missed both: the stack is empty, the walk is over
         }
     }
-    return res;
+}
+
+PT_DEV void walk_step(const DevScene& sc, const bool ANY_HIT, const Ray& ray, const RayPre& p, WalkState& w, const TravStack& stack) {
+    const PairData d = load_pair(sc.pairs, w.node);
+    const PairTest pt = test_pair(d, p, w.t);
+    const uint4 meta = d.meta;
+    bool go0 = pt.go0, go1 = pt.go1;
+    const bool hit_leaf0 = go0 & (meta.y != 0xFFFFFFFFu), hit_leaf1 = go1 & (meta.w != 0xFFFFFFFFu);
+    if (hit_leaf0 | hit_leaf1) {
+        if (hit_leaf0) {
+            for (unsigned i = meta.x; i < meta.x + meta.y; ++i)
+                if (hit_triangle(sc.tri_geom, i, ray, w.t, w.th)) { w.found = true; if (ANY_HIT) { w.done = true; return; } }
+            go0 = false;
+        }
+        if (hit_leaf1) {
+            for (unsigned i = meta.z; i < meta.z + meta.w; ++i)
+                if (hit_triangle(sc.tri_geom, i, ray, w.t, w.th)) { w.found = true; if (ANY_HIT) { w.done = true; return; } }
+            go1 = false;
+        }
+    }
+    if (go0 != go1) {
+        w.node = go0 ? meta.x : meta.z;
+    } else if (go0) {
+        unsigned nearc = meta.x, farc = meta.z;
+        if (pt.entry0 > pt.entry1) { nearc = meta.z; farc = meta.x; }
+        stack.lds[w.sp * stack.stride] = farc;
+        ++w.sp;
+        w.node = nearc;
+    } else {
+        if (w.sp == 0u) { w.done = true; return; }
+        --w.sp;
+        w.node = stack.lds[w.sp * stack.stride];
+    }
 }
 
 // ---- sphere / quad, kernels/geometry/sphere.cl:5-41, quad.cl:11-38 ------------------------------
@@ -1068,281 +1068,343 @@ PT_DEV f3 env_lookup(const DevScene& sc, f3 dir) {
 
 PT_DEV float power_heuristic(float pdf0, float pdf1) { return (pdf0 * pdf0) / (pdf0 * pdf0 + pdf1 * pdf1); }
 
-// ---- per-pixel path state in registers ---------------------------------------------------------------------
-// The closest hit of the ray a segment leaves behind.  The reference intersects that ray twice:
-// as the BSDF / phase probe of segment f (base.cl:57, :247) and again as the path ray of segment
-// f+1 (pathtracing.cl:27) -- same origin, same direction, same scene, hence the same result.
-// Inside one launch the second walk (BVH + spheres + quads) is skipped and this record is used.
-struct HitCache { bool valid, didHit, backside; float t; int mesh_id; f3 normal, pos; };
+// ---- per-pixel state in registers: the lane machine ------------------------------------------------------------
+// One lane owns one pixel and advances it segment by segment (one segment = one launch of the reference's
+// render_kernel for that pixel, kernels/main.cl:66-163 -> integrators/pathtracing.cl:4-120 + base.cl:31-260), as a
+// small state machine, so that a wave never waits for its deepest BVH walk.  One ITERATION of the wave runs, in order,
+//   A  lane_front          READY lanes: seeds + path (re)start (main.cl:108-136) once per segment; then either ask for
+//                          W1 = intersect_scene of the path ray (pathtracing.cl:27) when no cached hit exists (fresh
+//                          camera ray, continuation of a specular bounce), or -- with the hit in hand -- the medium
+//                          event / miss / emitter / BSDF or phase sampling of the segment; lanes that need no probe
+//                          finish their segment right here, the others ask for W2 = intersect_scene of the BSDF-sampled
+//                          probe ray (bsdfSample, base.cl:54-57) or of the phase-sampled one (base.cl:247)
+//   B  closest-hit walk    every lane with a W1 / W2 in flight steps through the tree; the phase ends when fewer than
+//                          FrameArgs::walk_min_lanes lanes are still walking and somebody has finished.  Unfinished
+//                          lanes keep their WalkState and go on in the next iteration's B; a finished lane runs
+//                          lane_closest_done (the rest of intersect_scene; result into Lane::h)
+//   C  lane_back           lanes whose probe is answered: MIS term of the probe, light sampling (lightSample base.cl:
+//                          79-134 / the probe part of volumePhaseSample), may ask for W3 = shadow ray (any hit)
+//   D  any-hit walk        as B, for the shadow rays
+//   E  lane_finish         radiance into acc, Russian roulette, bounce caps (pathtracing.cl:93-118, main.cl:142)
+// A lane with shallow rays completes one segment per iteration; a lane with a deep ray sits out A/C/E until its walk
+// is done and falls behind in frame number -- legal because pixels are independent: the seeds are a function of the
+// lane's own frame number (main.cl:108-109).  Which lanes walk together changes nothing a lane computes: results are
+// schedule-independent (tests/test_emu.py runs these same functions on the host with random phase lengths).
+//
+// Exact shortcuts relative to the reference's segment (each removes work, none changes a bit):
+//   * hit cache: the reference intersects the ray a segment leaves behind twice, as the probe of segment f and as the
+//     path ray of segment f+1 (same ray, same scene => same result).  Lane::h keeps the probe's hit: W1 only runs for
+//     rays that were never probed.
+//   * the shadow ray tests the primitives before the tree (shadow(), intersect.cl:94-152, is an OR of independent tests).
+//   * W3 is asked for last also at a medium scatter (the reference walks it before the probe): it only selects the
+//     radiance added to acc; no RNG draw or path state depends on it.
+// The RNG draws happen exactly in the reference's order.
+struct Hit { float t; f3 normal, pos; int mesh_id; bool didHit, backside; };
 
-struct Path {
-    HitCache hc;
-    f3 origin, dir;
-    float time, dist;
+enum { K_NONE = 0, K_SURFACE_MIS = 1, K_SCATTER = 2 };
+enum { ST_READY = 0, ST_WALKC = 1, ST_BACK = 2, ST_WALKS = 3, ST_FINISH = 4 };
+
+struct Lane {
+    // the pixel's RTD record (kernels/main.cl:117-119; what prt_read_state shows between launches)
     f3 mask;
     float acc[4];
-    unsigned total, samples;
-    unsigned diff, spec, trans, scatters;
+    unsigned total, samples, diff, spec, trans, scatters;
     bool wasSpecular, reset;
-};
-
-
-// ---- one segment: kernels/integrators/pathtracing.cl:4-120 + base.cl:31-260 -----------------------------
-// Written as four PHASES separated by the segment's three BVH walks, in the reference's order, so every
-// RNG draw happens exactly where it does there:
-//   seg_begin      (re)start the path if needed (main.cl:122-136); ask for W1 = closest hit of the path ray
-//                  (intersect_scene, pathtracing.cl:27) unless the hit cache holds it
-//   seg_after_w1   medium event, miss / emitter / surface, BSDF or phase sampling; ask for W2 = closest hit of
-//                  the BSDF-sampled probe ray (bsdfSample, base.cl:54-57) or of the phase-sampled probe ray
-//                  (volumePhaseSample, base.cl:247)
-//   seg_after_w2   MIS term of the probe, light sampling; ask for W3 = any-hit of the light shadow ray
-//                  (lightSample base.cl:115, volumeLightSample base.cl:219).  W3 only selects the radiance that
-//                  is added to acc: no RNG draw or path state depends on it, so for a medium scatter (where the
-//                  reference walks it BEFORE the probe) it is simply asked for last.
-//   seg_finish     radiance into acc, Russian roulette, bounce caps (pathtracing.cl:97-118, main.cl:142)
-// The megakernel runs the phases back to back with the walks inline; the wavefront pipeline suspends a pixel
-// at a walk that really enters the tree and resumes it in a later pass (SegCtx is what survives).
-struct SegCtx {
-    Ray ray;
+    // the segment's ray.  Inside a segment: Ray {origin, dir, t, time}; between segments the same four values ARE the
+    // TempRay {origin, dir, time = ray.t, dist = ray.time} of rayToTemp (main.cl:28) -- lane_front swaps (t, time) where
+    // tempToRay (main.cl:27) reads them back crosswise.
+    f3 origin, dir;
+    float t, time;
+    Hit h;                   // closest hit of a ray: of (origin, dir) when h_valid; of the probe after W2
+    bool h_valid;
     Rng rng;
-    Event e;
+    // the scatter event at the segment's vertex (SurfaceScatterEvent, header.cl:208-215) that later phases need
+    f3 wi, weight, n_shade;
+    float pdf;
+    unsigned sampledLobe;
     int mesh_id, kind;
-    bool terminate, surface, done, sh;
-    f3 emission;
-    float alpha;
-    f3 ms_p;                 // medium scatter position
-    LightSample rec;
-    PhaseSample ps;
-    f3 a;                    // surface: probe MIS term; scatter: unused
-    f3 a_vis, b_vis;         // light-sample term if the shadow ray is unoccluded (scatter / surface)
-    f3 sh_o, sh_d;
+    bool terminate, w2_ran;
+    f3 a;                    // MIS term of the probe ("a" of base.cl:170 / "b" of base.cl:259)
+    f3 vis;                  // light-sample term if the shadow ray is unoccluded
+    f3 sh_d;                 // shadow ray (origin: h.pos or ms_p)
     float sh_tmax;
+    bool sh;
+    f3 ms_p, ps_w, ps_weight;   // medium scatter: position, phase-sampled direction and weight
+    float ps_pdf;
+    WalkState w;             // the walk in flight
+    unsigned f;              // segments completed in this launch
+    int stage;
+    bool begun;              // seeds / restart of segment f done
+    bool fresh;              // the walk asked for has not started
+    bool w2;                 // the closest-hit walk in flight is the probe (W2), else the path ray (W1)
+    bool occluded;
 };
-enum { K_NONE = 0, K_SURFACE_MIS = 1, K_SCATTER = 2 };
 
-PT_DEV void seg_ctx_init(SegCtx& c) {
-    c.e.wi = c.e.wo = splat(0.0f); c.e.weight = splat(1.0f); c.e.pdf = 1.0f; c.e.sampledLobe = 0;
-    c.e.frame.normal = c.e.frame.tangent = c.e.frame.bitangent = splat(0.0f);
-    c.mesh_id = -1; c.kind = K_NONE;
-    c.terminate = c.surface = c.done = c.sh = false;
-    c.emission = splat(0.0f); c.alpha = 1.0f;
-    c.ms_p = splat(0.0f);
-    c.rec.d = splat(0.0f); c.rec.dist = 0.0f; c.rec.pdf = 1.0f;
-    c.ps.w = c.ps.weight = splat(0.0f); c.ps.pdf = 1.0f;
-    c.a = c.a_vis = c.b_vis = splat(0.0f);
-    c.sh_o = c.sh_d = splat(0.0f); c.sh_tmax = 0.0f;
+PT_DEV void lane_init(Lane& L) {
+    L.kind = K_NONE; L.mesh_id = -1; L.terminate = L.w2_ran = L.sh = false;
+    L.wi = L.weight = L.n_shade = L.a = L.vis = L.sh_d = L.ms_p = L.ps_w = L.ps_weight = splat(0.0f);
+    L.pdf = 1.0f; L.sampledLobe = 0u; L.sh_tmax = 0.0f; L.ps_pdf = 1.0f;
+    L.rng.s0 = L.rng.s1 = 0u;
+    L.h.t = 0.0f; L.h.normal = L.h.pos = splat(0.0f); L.h.mesh_id = -1; L.h.didHit = L.h.backside = false; L.h_valid = false;
+    L.w.node = L.w.sp = 0u; L.w.t = 0.0f; L.w.th.u = L.w.th.v = L.w.th.w = 0.0f; L.w.th.slot = 0u; L.w.found = false; L.w.done = true;
+    L.f = 0u; L.stage = ST_READY;
+    L.begun = L.fresh = L.w2 = L.occluded = false;
 }
 
-// kernels/main.cl:108-136: seeds, tempToRay, path (re)start.  Returns the W1 request.
-PT_DEV TravReq seg_begin(const DevCamera& cam, SegCtx& c, Path& st, int gx, int gy, int width, int full_height,
-                         unsigned frame, int random0, int random1) {
-    seg_ctx_init(c);
-    c.rng.s0 = (unsigned)gx * frame % 1000u + ((unsigned)random0 * 100u);     // main.cl:108-109
-    c.rng.s1 = (unsigned)gy * frame % 1000u + ((unsigned)random1 * 100u);
-    c.ray.origin = st.origin; c.ray.dir = st.dir;                              // tempToRay, main.cl:27
-    c.ray.normal = splat(0.0f); c.ray.pos = splat(0.0f);
-    c.ray.t = st.dist; c.ray.backside = false; c.ray.time = st.time;
-    if (st.reset || st.samples == 0) {                                         // main.cl:122-136
-        ++st.samples;
-        st.total = 0; st.diff = 0; st.spec = 0; st.trans = 0; st.scatters = 0;
-        st.wasSpecular = true;
-        st.reset = false;
-        st.mask = splat(1.0f);
-        st.hc.valid = false;
-        c.ray = create_cam_ray(gx, gy, width, full_height, cam, c.rng);
+// may this lane start (or go on with) a segment?  The "N spp" rule freezes a pixel at a segment boundary.
+PT_DEV bool lane_runnable(const FrameArgs& fa, const Lane& L) {
+    if (L.stage != ST_READY) return false;
+    if (L.begun) return true;
+    if (fa.spp_limit && L.reset && L.samples >= fa.spp_limit) return false;
+    return L.f < fa.n_frames;
+}
+
+// E (also reached straight from A by lanes that need no walk): the end of radiance() and of render_kernel.
+// `surface`: handleSurface sampled a direction (base.cl:183-191 still to do); `lit`: the shadow ray was unoccluded.
+template <bool MEDIUM>
+PT_DEV void lane_finish_segment(const DevScene& sc, Lane& L, f3 emission, const float alpha, const bool surface, bool done, const bool lit) {
+    if (L.kind == K_SURFACE_MIS) {
+        const f3 b = lit ? L.vis : splat(0.0f);
+        emission = emission + (L.a + b) * L.mask;                        // base.cl:170-171
+    } else if (MEDIUM && L.kind == K_SCATTER) {
+        const f3 a = lit ? L.vis : splat(0.0f);
+        emission = emission + (a + L.a) * L.mask;                        // pathtracing.cl:52-56
+        L.origin = L.ms_p;                                               // pathtracing.cl:58-61
+        L.dir = L.ps_w;
+        L.mask = L.mask * L.ps_weight;
     }
-    TravReq rq;
-    rq.want = !st.hc.valid; rq.o = c.ray.origin; rq.d = c.ray.dir; rq.tmax = PT_INF;
-    return rq;
+    if (surface && !done) {                                              // handleSurface tail, base.cl:183-191
+        L.wasSpecular = (L.sampledLobe & PRT_LOBE_SPECULAR) != 0;
+        L.mask = L.mask * L.weight;
+        L.diff = (L.diff + ((L.sampledLobe & (PRT_LOBE_DIFFUSE_R | PRT_LOBE_GLOSSY_R)) != 0)) & 0xffffu;
+        L.spec = (L.spec + ((L.sampledLobe & PRT_LOBE_SPECULAR_R) != 0)) & 0xffffu;
+        L.trans = (L.trans + ((L.sampledLobe & PRT_LOBE_TRANSMISSIVE) != 0)) & 0xffffu;
+        if (L.terminate) {
+            L.reset = true;
+            done = true;
+        } else {
+            L.scatters = 0;                                              // pathtracing.cl:93-94
+            ++L.total;
+        }
+    }
+    if (!done) {
+        const float roulettePdf = fmax3(L.mask);                         // pathtracing.cl:97-106
+        if (L.total > 2 && roulettePdf < 0.1f) {
+            if (next1D(L.rng) < roulettePdf) L.mask = L.mask / roulettePdf;
+            else { L.reset = true; done = true; }
+        }
+    }
+    if (!done) {
+        if (L.total >= (unsigned)sc.max_bounces || (int)L.diff >= sc.max_diff_bounces ||
+            (int)L.spec >= sc.max_spec_bounces || (int)L.trans >= sc.max_trans_bounces)
+            L.reset = true;                                              // pathtracing.cl:109-115
+    }
+    L.acc[0] += emission.x; L.acc[1] += emission.y; L.acc[2] += emission.z; L.acc[3] += alpha;   // main.cl:142
+    // rayToTemp (main.cl:28): {origin, dir, ray.t, ray.time} are already where the next segment finds them
+    ++L.f;
+    L.begun = false;
+    L.stage = ST_READY;
 }
 
+// A
 template <unsigned MATS, bool MEDIUM>
-PT_DEV TravReq seg_after_w1(const DevScene& sc, SegCtx& c, Path& st, const TravRes& r1) {
-    const unsigned am = active_mats<MATS>(sc);
-    Ray& ray = c.ray;
-    bool didHit;
-    if (st.hc.valid) {
-        didHit = st.hc.didHit; c.mesh_id = st.hc.mesh_id;
-        ray.t = st.hc.t; ray.normal = st.hc.normal; ray.pos = st.hc.pos; ray.backside = st.hc.backside;
-    } else {
-        didHit = finish_closest<(MATS & PT_MATS_SDF) != 0>(sc, ray, r1, c.mesh_id);
+PT_DEV void lane_front(const DevScene& sc, const DevCamera& cam, const FrameArgs& fa, Lane& L, int gx, int gy) {
+    if (!L.begun) {                                                      // main.cl:108-136
+        const unsigned frame = fa.first_frame + L.f;
+        const int random0 = fa.seed_pairs[2 * L.f], random1 = fa.seed_pairs[2 * L.f + 1];
+        L.rng.s0 = (unsigned)gx * frame % 1000u + ((unsigned)random0 * 100u);      // main.cl:108-109
+        L.rng.s1 = (unsigned)gy * frame % 1000u + ((unsigned)random1 * 100u);
+        { const float tt = L.t; L.t = L.time; L.time = tt; }                        // tempToRay after rayToTemp, main.cl:27-28
+        if (L.reset || L.samples == 0) {                                            // main.cl:122-136
+            ++L.samples;
+            L.total = 0; L.diff = 0; L.spec = 0; L.trans = 0; L.scatters = 0;
+            L.wasSpecular = true;
+            L.reset = false;
+            L.mask = splat(1.0f);
+            L.h_valid = false;
+            const Ray cr = create_cam_ray(gx, gy, fa.width, fa.full_height, cam, L.rng);
+            L.origin = cr.origin; L.dir = cr.dir; L.t = cr.t; L.time = cr.time;
+        }
+        L.begun = true;
     }
-    st.hc.valid = false;
-    const Mat mat = load_mat((c.mesh_id + 1) ? &sc.mats[c.mesh_id + 1] : &sc.mats[sc.n_meshes + 1]);
-    TravReq rq2;
-    rq2.want = false; rq2.o = rq2.d = splat(0.0f); rq2.tmax = PT_INF;
-    bool scattered = false;
+    if (!L.h_valid) {                                                    // W1: intersect_scene of the path ray, pathtracing.cl:27
+        L.stage = ST_WALKC; L.fresh = true; L.w2 = false;
+        return;
+    }
+    const unsigned am = active_mats<MATS>(sc);
+    Ray ray;                                                             // the path ray with its hit
+    ray.origin = L.origin; ray.dir = L.dir; ray.time = L.time;
+    ray.t = L.h.t; ray.normal = L.h.normal; ray.pos = L.h.pos; ray.backside = L.h.backside;
+    const bool didHit = L.h.didHit;
+    L.mesh_id = L.h.mesh_id;
+    L.t = L.h.t;
+    L.h_valid = false;
+    L.kind = K_NONE; L.terminate = false; L.w2_ran = false; L.sh = false;
+    L.a = splat(0.0f); L.vis = splat(0.0f);
+    const Mat mat = load_mat((L.mesh_id + 1) ? &sc.mats[L.mesh_id + 1] : &sc.mats[sc.n_meshes + 1]);
+    f3 emission = splat(0.0f);
+    float alpha = 1.0f;
     if (MEDIUM) {
         MediumSample ms;
-        medium_sample_distance(sc, ms, ray, c.rng);
-        st.mask = st.mask * ms.weight;
-        if (!ms.exited && (int)st.scatters < sc.max_scattering_events) {
-            scattered = true;
-            c.kind = K_SCATTER;
-            c.ms_p = ms.p;
-            st.scatters = (st.scatters + 1u) & 0xffffu;
-            st.wasSpecular = false;
+        medium_sample_distance(sc, ms, ray, L.rng);
+        L.mask = L.mask * ms.weight;
+        if (!ms.exited && (int)L.scatters < sc.max_scattering_events) {
+            L.kind = K_SCATTER;
+            L.ms_p = ms.p;
+            L.scatters = (L.scatters + 1u) & 0xffffu;
+            L.wasSpecular = false;
             // volumeLightSample, base.cl:194-230 (samples the light from ray.pos, not ms.p: SURVEY s9-Q4)
-            if (sample_light0(sc, ray.pos, c.rec, c.rng)) {
-                const float fv = phase_value(sc, ray.dir, c.rec.d);
+            LightSample rec;
+            if (sample_light0(sc, ray.pos, rec, L.rng)) {
+                const float fv = phase_value(sc, ray.dir, rec.d);
                 const f3 f = splat(fv);
                 if (!(dot(f, f) == 0.0f)) {
-                    c.sh = true; c.sh_o = ms.p; c.sh_d = c.rec.d; c.sh_tmax = c.rec.dist;
+                    L.sh = true; L.sh_d = rec.d; L.sh_tmax = rec.dist;
                     const Mat lm = load_mat(&sc.mats[sc.light_mesh + 1]);
-                    const f3 tr = vexp(splat(sc.fog_sigma_t) * (-1.0f * c.rec.dist));
-                    const f3 contribution = tr * lm.color * f * power_heuristic(c.rec.pdf, fv);
-                    c.a_vis = contribution / c.rec.pdf;
+                    const f3 tr = vexp(splat(sc.fog_sigma_t) * (-1.0f * rec.dist));
+                    const f3 contribution = tr * lm.color * f * power_heuristic(rec.pdf, fv);
+                    L.vis = contribution / rec.pdf;
                 }
             }
-            phase_sample(sc, ray.dir, c.ps, c.rng);                      // volumePhaseSample, base.cl:232-260
-            rq2.want = true; rq2.o = ms.p; rq2.d = c.ps.w; rq2.tmax = PT_INF;
+            PhaseSample ps;
+            phase_sample(sc, ray.dir, ps, L.rng);                        // volumePhaseSample, base.cl:232-260
+            L.ps_w = ps.w; L.ps_weight = ps.weight; L.ps_pdf = ps.pdf;
+            L.w2_ran = true;
+            L.stage = ST_WALKC; L.fresh = true; L.w2 = true;
+            return;
         }
     }
-    if (!scattered) {
-        if (!didHit) {
-            st.reset = true;
-            if (sc.alpha_testing) { c.emission = splat(0.0f); c.alpha = 0.0f; }
-            else c.emission = st.mask * env_lookup(sc, ray.dir);
-            c.done = true;
-        } else if ((am & PRT_MAT_LIGHT) && (mat.t & PRT_MAT_LIGHT)) {
-            if (st.wasSpecular) c.emission = c.emission + mat.color * st.mask;
-            st.reset = true;
-            c.done = true;
-        } else {
-            c.surface = true;
-            c.e.frame = make_frame(ray.normal);                         // makeLocalScatterEvent, base.cl:11-14
-            c.e.wi = to_local(c.e.frame, -ray.dir);
-            if ((am & PRT_MAT_LIGHT) && (mat.lobes & ~(PRT_LOBE_SPECULAR | PRT_LOBE_FORWARD) & 0xffu)) {
-                c.kind = K_SURFACE_MIS;                                 // handleSurface, base.cl:168-172
-                if (!bsdf_sample2<MATS>(sc, c.e, ray, mat, c.rng)) {    // bsdfSample, base.cl:31-77
-                    c.terminate = true;
-                } else {
-                    ray.origin = ray.pos;
-                    ray.dir = to_global(c.e.frame, c.e.wo);
-                    rq2.want = true; rq2.o = ray.origin; rq2.d = ray.dir; rq2.tmax = PT_INF;
-                }
-            } else {
-                if (!bsdf_sample2<MATS>(sc, c.e, ray, mat, c.rng)) {    // base.cl:175-181
-                    st.reset = true;
-                    c.done = true;
-                    c.surface = false;
-                } else {
-                    ray.origin = ray.pos;
-                    ray.dir = to_global(c.e.frame, c.e.wo);
-                }
-            }
-        }
+    if (!didHit) {                                                       // pathtracing.cl:66-75
+        L.reset = true;
+        if (sc.alpha_testing) { emission = splat(0.0f); alpha = 0.0f; }
+        else emission = L.mask * env_lookup(sc, ray.dir);
+        lane_finish_segment<MEDIUM>(sc, L, emission, alpha, false, true, false);
+        return;
     }
-    return rq2;
+    if ((am & PRT_MAT_LIGHT) && (mat.t & PRT_MAT_LIGHT)) {               // pathtracing.cl:77-84
+        if (L.wasSpecular) emission = emission + mat.color * L.mask;
+        L.reset = true;
+        lane_finish_segment<MEDIUM>(sc, L, emission, alpha, false, true, false);
+        return;
+    }
+    Event e;                                                             // makeLocalScatterEvent, base.cl:11-14
+    e.wo = splat(0.0f); e.weight = splat(1.0f); e.pdf = 1.0f; e.sampledLobe = 0;
+    e.frame = make_frame(ray.normal);
+    e.wi = to_local(e.frame, -ray.dir);
+    const bool mis = (am & PRT_MAT_LIGHT) && (mat.lobes & ~(PRT_LOBE_SPECULAR | PRT_LOBE_FORWARD) & 0xffu);
+    const bool ok = bsdf_sample2<MATS>(sc, e, ray, mat, L.rng);          // bsdfSample base.cl:31-77 / handleSurface base.cl:175-181
+    L.wi = e.wi; L.weight = e.weight; L.pdf = e.pdf; L.sampledLobe = e.sampledLobe; L.n_shade = ray.normal;
+    if (ok) {
+        L.origin = ray.pos;
+        L.dir = to_global(e.frame, e.wo);
+    }
+    if (mis) {                                                           // handleSurface, base.cl:168-172
+        L.kind = K_SURFACE_MIS;
+        if (ok) { L.w2_ran = true; L.stage = ST_WALKC; L.fresh = true; L.w2 = true; }
+        else { L.terminate = true; L.stage = ST_BACK; }
+    } else if (ok) {
+        lane_finish_segment<MEDIUM>(sc, L, emission, alpha, true, false, false);
+    } else {
+        L.reset = true;
+        lane_finish_segment<MEDIUM>(sc, L, emission, alpha, false, true, false);
+    }
 }
 
-// `w2_ran`: W2 was asked for (r2 is its result).  Returns the W3 (shadow, any-hit) request; when the
-// primitives already occlude the shadow ray the request is not made and the light term is dropped.
+// the ray of the closest-hit walk in flight (`normal` = what intersect_scene finds in ray->normal on entry)
+template <bool MEDIUM>
+PT_DEV Ray lane_closest_ray(const Lane& L) {
+    Ray r;
+    r.pos = splat(0.0f); r.backside = false; r.t = PT_INF; r.time = 0.0f;
+    if (MEDIUM && L.w2 && L.kind == K_SCATTER) {                          // volumePhaseSample's probe, base.cl:243-247
+        r.origin = L.ms_p; r.dir = L.ps_w; r.normal = splat(0.0f);
+    } else {
+        r.origin = L.origin; r.dir = L.dir;
+        r.normal = L.w2 ? L.h.normal : splat(0.0f);                       // bsdfSample re-aims `ray` itself (base.cl:54-57); tempToRay zeroes it
+    }
+    return r;
+}
+
+// B, a lane whose closest-hit walk is over: the rest of intersect_scene (intersect.cl:167-236)
 template <unsigned MATS, bool MEDIUM>
-PT_DEV TravReq seg_after_w2(const DevScene& sc, SegCtx& c, Path& st, const bool w2_ran, const TravRes& r2) {
-    Ray& ray = c.ray;
-    if (c.kind == K_SURFACE_MIS) {
-        const Mat mat = load_mat((c.mesh_id + 1) ? &sc.mats[c.mesh_id + 1] : &sc.mats[sc.n_meshes + 1]);
-        if (w2_ran) {                                                    // the probe ray, base.cl:54-75
-            int mid;
-            const bool hit2 = finish_closest<(MATS & PT_MATS_SDF) != 0>(sc, ray, r2, mid);
-            st.hc.valid = true; st.hc.didHit = hit2; st.hc.backside = ray.backside; st.hc.t = ray.t; st.hc.mesh_id = mid;
-            st.hc.normal = ray.normal; st.hc.pos = ray.pos;
-            if (hit2) {
-                const unsigned lbits = sc.mats[mid + 1].bits;
-                if (lbits & PRT_MAT_LIGHT) {
-                    const Mat lm = load_mat(&sc.mats[mid + 1]);
-                    c.a = lm.color * c.e.weight * power_heuristic(c.e.pdf, direct_pdf_mesh(sc, mid, ray.dir, ray.pos));
-                    if (MEDIUM) c.a = c.a * vexp(splat(sc.fog_sigma_t) * (-1.0f * ray.t));
-                }
-            }
-        }
-        // lightSample, base.cl:79-134 (from ray.pos = the probe ray's hit point: SURVEY s9-Q4)
-        if (sample_light0(sc, ray.pos, c.rec, c.rng)) {
-            c.e.wo = to_local(c.e.frame, c.rec.d);
-            const f3 fr = bsdf_eval2<MATS>(sc, c.e, mat);
-            if (!(dot(fr, fr) == 0.0f)) {
-                c.sh = true; c.sh_o = ray.pos; c.sh_d = c.rec.d; c.sh_tmax = c.rec.dist;
-                const Mat lm = load_mat(&sc.mats[sc.light_mesh + 1]);
-                f3 contribution = lm.color * fr;
-                if (MEDIUM) contribution = contribution * vexp(splat(sc.fog_sigma_t) * (-1.0f * c.rec.dist));
-                contribution = contribution * power_heuristic(c.rec.pdf, bsdf_pdf<MATS>(sc, c.e, mat));
-                c.b_vis = contribution / c.rec.pdf;
-            }
-        }
-    } else if (c.kind == K_SCATTER) {
-        Ray sRay;
-        sRay.origin = c.ms_p; sRay.dir = c.ps.w; sRay.normal = splat(0.0f); sRay.pos = splat(0.0f); sRay.backside = false;
-        sRay.t = PT_INF; sRay.time = 0.0f;
-        int mid;
-        const bool hit3 = finish_closest<(MATS & PT_MATS_SDF) != 0>(sc, sRay, r2, mid);
-        st.hc.valid = true; st.hc.didHit = hit3; st.hc.backside = sRay.backside; st.hc.t = sRay.t; st.hc.mesh_id = mid;
-        st.hc.normal = sRay.normal; st.hc.pos = sRay.pos;
-        if (hit3) {
+PT_DEV void lane_closest_done(const DevScene& sc, Lane& L) {
+    TravRes r;
+    r.found = L.w.found; r.t = L.w.t; r.th = L.w.th;
+    Ray wr = lane_closest_ray<MEDIUM>(L);
+    int mid;
+    const bool hit = finish_closest<(MATS & PT_MATS_SDF) != 0>(sc, wr, r, mid);
+    L.h.t = wr.t; L.h.normal = wr.normal; L.h.pos = wr.pos; L.h.mesh_id = mid; L.h.didHit = hit; L.h.backside = wr.backside;
+    L.h_valid = true;
+    if (!L.w2) {
+        L.stage = ST_READY;                                              // lane_front goes on with the hit in the next iteration
+    } else {
+        if (!(MEDIUM && L.kind == K_SCATTER)) L.t = wr.t;                // bsdfSample's intersect_scene works on `ray` itself
+        L.stage = ST_BACK;
+    }
+}
+
+// C
+template <unsigned MATS, bool MEDIUM>
+PT_DEV void lane_back(const DevScene& sc, Lane& L) {
+    f3 sh_o = L.h.pos;
+    if (L.kind == K_SURFACE_MIS) {
+        const Mat mat = load_mat((L.mesh_id + 1) ? &sc.mats[L.mesh_id + 1] : &sc.mats[sc.n_meshes + 1]);
+        if (L.w2_ran && L.h.didHit) {                                    // the probe ray, base.cl:58-75
+            const int mid = L.h.mesh_id;
             const unsigned lbits = sc.mats[mid + 1].bits;
             if (lbits & PRT_MAT_LIGHT) {
                 const Mat lm = load_mat(&sc.mats[mid + 1]);
-                const f3 tr = vexp(splat(sc.fog_sigma_t) * (-1.0f * sRay.t));
-                c.a = tr * lm.color * c.ps.weight * power_heuristic(c.ps.pdf, direct_pdf_mesh(sc, mid, sRay.dir, c.ms_p));   // "b" of base.cl:259
+                L.a = lm.color * L.weight * power_heuristic(L.pdf, direct_pdf_mesh(sc, mid, L.dir, L.h.pos));
+                if (MEDIUM) L.a = L.a * vexp(splat(sc.fog_sigma_t) * (-1.0f * L.t));
+            }
+        }
+        // lightSample, base.cl:79-134 (from ray.pos = the probe ray's hit point: SURVEY s9-Q4)
+        LightSample rec;
+        if (sample_light0(sc, L.h.pos, rec, L.rng)) {
+            Event e;
+            e.frame = make_frame(L.n_shade);
+            e.wi = L.wi; e.weight = L.weight; e.pdf = L.pdf; e.sampledLobe = L.sampledLobe;
+            e.wo = to_local(e.frame, rec.d);
+            const f3 fr = bsdf_eval2<MATS>(sc, e, mat);
+            if (!(dot(fr, fr) == 0.0f)) {
+                L.sh = true; L.sh_d = rec.d; L.sh_tmax = rec.dist;
+                const Mat lm = load_mat(&sc.mats[sc.light_mesh + 1]);
+                f3 contribution = lm.color * fr;
+                if (MEDIUM) contribution = contribution * vexp(splat(sc.fog_sigma_t) * (-1.0f * rec.dist));
+                contribution = contribution * power_heuristic(rec.pdf, bsdf_pdf<MATS>(sc, e, mat));
+                L.vis = contribution / rec.pdf;
+            }
+        }
+    } else if (MEDIUM && L.kind == K_SCATTER) {
+        sh_o = L.ms_p;
+        if (L.h.didHit) {
+            const int mid = L.h.mesh_id;
+            const unsigned lbits = sc.mats[mid + 1].bits;
+            if (lbits & PRT_MAT_LIGHT) {
+                const Mat lm = load_mat(&sc.mats[mid + 1]);
+                const f3 tr = vexp(splat(sc.fog_sigma_t) * (-1.0f * L.h.t));
+                L.a = tr * lm.color * L.ps_weight * power_heuristic(L.ps_pdf, direct_pdf_mesh(sc, mid, L.ps_w, L.ms_p));   // "b" of base.cl:259
             }
         }
     }
-    TravReq rq3;
-    rq3.want = false; rq3.o = c.sh_o; rq3.d = c.sh_d; rq3.tmax = c.sh_tmax;
-    // shadow(), intersect.cl:94-152: BVH, sphere and quad tests are independent and the any-hit walk never
-    // shrinks ray.t, so the boolean does not depend on their order: the 7 primitives first.
-    if (c.sh) {
-        if (finish_shadow<(MATS & PT_MATS_SDF) != 0>(sc, c.sh_o, c.sh_d, c.sh_tmax)) rq3.want = true;
-        else c.sh = false;                                               // occluded by a primitive
-    }
-    return rq3;
+    // shadow(), intersect.cl:94-152: BVH, sphere and quad tests are independent and the any-hit walk never shrinks
+    // ray.t, so the boolean does not depend on their order: the primitives first, the tree only if they do not occlude
+    if (L.sh && !finish_shadow<(MATS & PT_MATS_SDF) != 0>(sc, sh_o, L.sh_d, L.sh_tmax)) L.sh = false;
+    if (L.sh) { L.stage = ST_WALKS; L.fresh = true; }
+    else { L.stage = ST_FINISH; L.occluded = false; }
 }
 
-// `occluded`: result of W3 (ignored unless c.sh)
-PT_DEV void seg_finish(const DevScene& sc, SegCtx& c, Path& st, const bool occluded) {
-    Ray& ray = c.ray;
-    const bool lit = c.sh && !occluded;
-    if (c.kind == K_SURFACE_MIS) {
-        const f3 b = lit ? c.b_vis : splat(0.0f);
-        c.emission = c.emission + (c.a + b) * st.mask;                   // base.cl:170-171
-    } else if (c.kind == K_SCATTER) {
-        const f3 a = lit ? c.a_vis : splat(0.0f);
-        c.emission = c.emission + (a + c.a) * st.mask;                   // pathtracing.cl:52-56
-        ray.origin = c.ms_p;                                             // pathtracing.cl:58-61
-        ray.dir = c.ps.w;
-        st.mask = st.mask * c.ps.weight;
-    }
-    if (c.surface && !c.done) {                                          // handleSurface tail, base.cl:183-191
-        const Event& e = c.e;
-        st.wasSpecular = (e.sampledLobe & PRT_LOBE_SPECULAR) != 0;
-        st.mask = st.mask * e.weight;
-        st.diff = (st.diff + ((e.sampledLobe & (PRT_LOBE_DIFFUSE_R | PRT_LOBE_GLOSSY_R)) != 0)) & 0xffffu;
-        st.spec = (st.spec + ((e.sampledLobe & PRT_LOBE_SPECULAR_R) != 0)) & 0xffffu;
-        st.trans = (st.trans + ((e.sampledLobe & PRT_LOBE_TRANSMISSIVE) != 0)) & 0xffffu;
-        if (c.terminate) {
-            st.reset = true;
-            c.done = true;
-        } else {
-            st.scatters = 0;                                             // pathtracing.cl:93-94
-            ++st.total;
-        }
-    }
-    if (!c.done) {
-        const float roulettePdf = fmax3(st.mask);                        // pathtracing.cl:97-106
-        if (st.total > 2 && roulettePdf < 0.1f) {
-            if (next1D(c.rng) < roulettePdf) st.mask = st.mask / roulettePdf;
-            else { st.reset = true; c.done = true; }
-        }
-    }
-    if (!c.done) {
-        if (st.total >= (unsigned)sc.max_bounces || (int)st.diff >= sc.max_diff_bounces ||
-            (int)st.spec >= sc.max_spec_bounces || (int)st.trans >= sc.max_trans_bounces)
-            st.reset = true;                                             // pathtracing.cl:109-115
-    }
-    st.acc[0] += c.emission.x; st.acc[1] += c.emission.y; st.acc[2] += c.emission.z; st.acc[3] += c.alpha;   // main.cl:142
-    st.origin = ray.origin; st.dir = ray.dir;                            // rayToTemp, main.cl:28:
-    st.time = ray.t;                                                     //   {origin, dir, ray.t, ray.time}
-    st.dist = ray.time;                                                  //   -> {origin, dir, time, dist}
+template <bool MEDIUM>
+PT_DEV Ray lane_shadow_ray(const Lane& L) {
+    Ray r;
+    r.origin = (MEDIUM && L.kind == K_SCATTER) ? L.ms_p : L.h.pos;
+    r.dir = L.sh_d; r.normal = splat(0.0f); r.pos = splat(0.0f); r.t = L.sh_tmax; r.backside = false; r.time = 0.0f;
+    return r;
+}
+
+// E
+template <bool MEDIUM>
+PT_DEV void lane_finish(const DevScene& sc, Lane& L) {
+    lane_finish_segment<MEDIUM>(sc, L, splat(0.0f), 1.0f, L.kind == K_SURFACE_MIS, false, L.sh && !L.occluded);
 }
 
 }  // namespace dev

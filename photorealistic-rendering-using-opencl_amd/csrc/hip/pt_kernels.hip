@@ -1,4 +1,4 @@
-// pt_kernels.hip -- gfx950 kernels of libprt (see pt_device.h for the arithmetic contract).
+// pt_kernels.hip -- gfx950 kernels of libprt (see pt_device.h for the arithmetic contract and the lane machine).
 //
 //   render_kernel<MATS, MEDIUM>   the hot path: one lane = one pixel, n_frames segments per launch
 //   state_to_rtd / rtd_to_state   80 B/px SoA planes <-> the reference's 112 B RTD records
@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <cstring>
 
 #include "pt_device.h"
 #include "pt_launch.h"
@@ -22,77 +23,102 @@ using namespace dev;
 #ifndef PT_MIN_WAVES
 #define PT_MIN_WAVES 4      // waves per SIMD the register allocator must leave room for (128 VGPRs)
 #endif
-#ifndef PT_BLOCK
 #define PT_BLOCK 64         // threads per workgroup: ONE wave.  A workgroup's slot (LDS, dispatch) frees only when its last wave
                             // ends, and waves over the mesh run ~3x longer than waves over a wall: one-wave groups +4 % over 256
-#endif
 
-// WAVES = waves per SIMD the register allocator leaves room for: 4 (128 VGPRs) is best while the tree sits in L2;
-// on a tree of tens of MB every node step is a trip to the Infinity Cache or HBM and 5 waves (96 VGPRs, more
-// spills, more latency hidden) win +13 % (871 k triangles); 6 and 8 lose again.
+// One wave = one 8x8 tile; every lane runs the lane machine of pt_device.h on its pixel until it has done its n_frames
+// segments (or froze).  What is wave-level here is only the SCHEDULE: when the two walk phases of an iteration end.
+//   walk phase rule: go on while at least fa.walk_min_lanes lanes are still walking; below that, stop as soon as the
+//   iteration has something else to do (a lane finished its walk in this phase, or lanes are waiting in a later stage).
+//   A lane cut off keeps its WalkState and LDS stack and resumes in the same phase of the next iteration.
+// WAVES = waves per SIMD the register allocator leaves room for.
 template <unsigned MATS, bool MEDIUM, int WAVES>
 __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene sc, const DevCamera cam, const DevState S,
                                                                  const FrameArgs fa, float4* __restrict__ fb) {
-    // workgroup tile: 8x8 pixels per wave; 1 wave (PT_BLOCK 64), 1x2 (128) or 2x2 (256) waves per workgroup
-    constexpr int TILE_H = PT_BLOCK >= 128 ? 16 : 8, TILE_W = PT_BLOCK / TILE_H, WAVES_X = TILE_W / 8;
-    const int tiles_x = (fa.width + TILE_W - 1) / TILE_W;
+    const int tiles_x = (fa.width + 7) / 8;
     const unsigned tile = blockIdx.x * fa.tile_stride + fa.tile_first;
     const int tile_x = (int)(tile % (unsigned)tiles_x), tile_y = (int)(tile / (unsigned)tiles_x);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int lx = tile_x * TILE_W + (wave % WAVES_X) * 8 + (lane & 7);
-    const int ly = tile_y * TILE_H + (wave / WAVES_X) * 8 + (lane >> 3);
-    static_assert(PT_BLOCK == 64, "the end-of-launch ticket counts one wave per workgroup, each with a pixel inside the frame");
+    const int lane = threadIdx.x & 63;
+    const int lx = tile_x * 8 + (lane & 7);
+    const int ly = tile_y * 8 + (lane >> 3);
     if (lx >= fa.width || ly >= fa.rows) return;                // no barriers in this kernel
     const size_t id = (size_t)ly * (size_t)fa.width + (size_t)lx;
     const int gx = lx;
     const int gy = fa.row0 + (ly / fa.block_rows * fa.n_parts + fa.part) * fa.block_rows + ly % fa.block_rows;
 
-    Path st;
-    st.hc.valid = false; st.hc.didHit = false; st.hc.backside = false; st.hc.t = 0.0f; st.hc.mesh_id = -1;
-    st.hc.normal = splat(0.0f); st.hc.pos = splat(0.0f);
+    Lane L;
+    lane_init(L);
     {
         const float4 a = S.q0[id], b = S.q1[id], c = S.q2[id], d = S.q3[id];
         const uint4 e = S.q4[id];
-        st.origin = F3(a.x, a.y, a.z); st.time = a.w;
-        st.dir = F3(b.x, b.y, b.z); st.dist = b.w;
-        st.mask = F3(c.x, c.y, c.z); st.total = prt_f2u(c.w);
-        st.acc[0] = d.x; st.acc[1] = d.y; st.acc[2] = d.z; st.acc[3] = d.w;
-        st.samples = e.x;
-        st.diff = e.y & 0xffffu; st.spec = e.y >> 16;
-        st.trans = e.z & 0xffffu; st.scatters = e.z >> 16;
-        st.wasSpecular = (e.w & 1u) != 0; st.reset = (e.w & 2u) != 0;
+        L.origin = F3(a.x, a.y, a.z); L.t = a.w;                // TempRay.time = ray.t of the last segment (main.cl:28)
+        L.dir = F3(b.x, b.y, b.z); L.time = b.w;                // TempRay.dist = ray.time
+        L.mask = F3(c.x, c.y, c.z); L.total = prt_f2u(c.w);
+        L.acc[0] = d.x; L.acc[1] = d.y; L.acc[2] = d.z; L.acc[3] = d.w;
+        L.samples = e.x;
+        L.diff = e.y & 0xffffu; L.spec = e.y >> 16;
+        L.trans = e.z & 0xffffu; L.scatters = e.z >> 16;
+        L.wasSpecular = (e.w & 1u) != 0; L.reset = (e.w & 2u) != 0;
     }
     extern __shared__ unsigned lds_stack[];                     // sc.stack_levels x PT_BLOCK, sized by the launch
     TravStack stk;
     stk.lds = lds_stack + threadIdx.x; stk.stride = PT_BLOCK;
-    bool ran = false;
-    for (unsigned f = 0; f < fa.n_frames; ++f) {
-        if (fa.spp_limit && st.reset && st.samples >= fa.spp_limit) break;     // frozen (the "N spp" rule)
-        SegCtx c;
-        TravRes none;
-        none.found = false; none.t = PT_INF; none.th.u = none.th.v = none.th.w = 0.0f; none.th.slot = 0;
-        const TravReq rq1 = seg_begin(cam, c, st, gx, gy, fa.width, fa.full_height, fa.first_frame + f,
-                                      fa.seed_pairs[2 * f], fa.seed_pairs[2 * f + 1]);
-        const TravRes r1 = rq1.want ? walk(sc, false, rq1, stk) : none;
-        const TravReq rq2 = seg_after_w1<MATS, MEDIUM>(sc, c, st, r1);
-        const TravRes r2 = rq2.want ? walk(sc, false, rq2, stk) : none;
-        const TravReq rq3 = seg_after_w2<MATS, MEDIUM>(sc, c, st, rq2.want, r2);
-        const bool occluded = rq3.want ? walk(sc, true, rq3, stk).found : false;
-        seg_finish(sc, c, st, occluded);
-        ran = true;
+    const unsigned T = fa.walk_min_lanes;
+    for (;;) {
+        const bool runnable = lane_runnable(fa, L);
+        if (!__any(runnable || L.stage != ST_READY)) break;     // every lane has done its frames (or is frozen)
+        if (runnable) lane_front<MATS, MEDIUM>(sc, cam, fa, L, gx, gy);                                  // A
+        {                                                                                                 // B
+            const bool walking = L.stage == ST_WALKC;
+            const Ray wr = lane_closest_ray<MEDIUM>(L);
+            const RayPre p = ray_pre(wr);
+            if (walking && L.fresh) { walk_begin(sc, false, wr, PT_INF, p, L.w, stk); L.fresh = false; }
+            const bool go = walking && !L.w.done;
+            const unsigned n_start = (unsigned)__popcll(__ballot(go));
+            const bool other_work = __any((walking && L.w.done) || L.stage == ST_BACK);
+            if (go) {
+                for (;;) {
+                    walk_step(sc, false, wr, p, L.w, stk);
+                    if (L.w.done) break;
+                    const unsigned n_act = (unsigned)__popcll(__ballot(1));
+                    if (n_act < T && (n_act < n_start || other_work)) break;
+                }
+            }
+            if (walking && L.w.done) lane_closest_done<MATS, MEDIUM>(sc, L);
+        }
+        if (L.stage == ST_BACK) lane_back<MATS, MEDIUM>(sc, L);                                          // C
+        {                                                                                                 // D
+            const bool walking = L.stage == ST_WALKS;
+            const Ray wr = lane_shadow_ray<MEDIUM>(L);
+            const RayPre p = ray_pre(wr);
+            if (walking && L.fresh) { walk_begin(sc, true, wr, wr.t, p, L.w, stk); L.fresh = false; }
+            const bool go = walking && !L.w.done;
+            const unsigned n_start = (unsigned)__popcll(__ballot(go));
+            const bool other_work = __any((walking && L.w.done) || L.stage == ST_FINISH);
+            if (go) {
+                for (;;) {
+                    walk_step(sc, true, wr, p, L.w, stk);
+                    if (L.w.done) break;
+                    const unsigned n_act = (unsigned)__popcll(__ballot(1));
+                    if (n_act < T && (n_act < n_start || other_work)) break;
+                }
+            }
+            if (walking && L.w.done) { L.occluded = L.w.found; L.stage = ST_FINISH; }
+        }
+        if (L.stage == ST_FINISH) lane_finish<MEDIUM>(sc, L);                                            // E
     }
-    if (ran) {
-        S.q0[id] = make_float4(st.origin.x, st.origin.y, st.origin.z, st.time);
-        S.q1[id] = make_float4(st.dir.x, st.dir.y, st.dir.z, st.dist);
-        S.q2[id] = make_float4(st.mask.x, st.mask.y, st.mask.z, prt_u2f(st.total));
-        S.q3[id] = make_float4(st.acc[0], st.acc[1], st.acc[2], st.acc[3]);
-        S.q4[id] = make_uint4(st.samples, (st.diff & 0xffffu) | (st.spec << 16), (st.trans & 0xffffu) | (st.scatters << 16),
-                              (st.wasSpecular ? 1u : 0u) | (st.reset ? 2u : 0u));
-        const float ns = (float)st.samples;                                    // write_imagef, main.cl:159
-        fb[id] = make_float4(st.acc[0] / ns, st.acc[1] / ns, st.acc[2] / ns, st.acc[3] / ns);
+    if (L.f) {
+        S.q0[id] = make_float4(L.origin.x, L.origin.y, L.origin.z, L.t);
+        S.q1[id] = make_float4(L.dir.x, L.dir.y, L.dir.z, L.time);
+        S.q2[id] = make_float4(L.mask.x, L.mask.y, L.mask.z, prt_u2f(L.total));
+        S.q3[id] = make_float4(L.acc[0], L.acc[1], L.acc[2], L.acc[3]);
+        S.q4[id] = make_uint4(L.samples, (L.diff & 0xffffu) | (L.spec << 16), (L.trans & 0xffffu) | (L.scatters << 16),
+                              (L.wasSpecular ? 1u : 0u) | (L.reset ? 2u : 0u));
+        const float ns = (float)L.samples;                                     // write_imagef, main.cl:159
+        fb[id] = make_float4(L.acc[0] / ns, L.acc[1] / ns, L.acc[2] / ns, L.acc[3] / ns);
     }
     if (fa.unfinished) {
-        const bool unfinished = !(fa.spp_limit && st.reset && st.samples >= fa.spp_limit);
+        const bool unfinished = !(fa.spp_limit && L.reset && L.samples >= fa.spp_limit);
         const unsigned long long m = __ballot(unfinished);
         if (lane == (int)__builtin_ctzll(__ballot(1))) {
             // returning atomic: its value is back only once the add has been performed at the device's coherence point
@@ -101,268 +127,13 @@ __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene 
                 // fence -- a device-scope fence writes back and invalidates this XCD's L2, 2.5 % when every wave does it)
                 // The last wave of the launch hands the total to the host and leaves the counters clean for the next launch
                 // (every 8x8 tile holds at least one pixel of the frame, so every wave of the grid gets here).
-                if (atomicAdd(fa.unfinished + 1, 1ull) == (unsigned long long)gridDim.x * (PT_BLOCK / 64) - 1ull) {
+                if (atomicAdd(fa.unfinished + 1, 1ull) == (unsigned long long)gridDim.x - 1ull) {
                     const unsigned long long total = atomicExch(fa.unfinished, 0ull);
                     atomicExch(fa.unfinished + 1, 0ull);
                     *reinterpret_cast<volatile unsigned long long*>(fa.unfinished_host) = total;   // visible to the host at kernel end
                 }
             }
         }
-    }
-}
-
-// ======================================================================================================
-// Wavefront pipeline: wf_shade_kernel (all pixels: resume or start a segment, run phases until a walk that
-// really enters the tree, then suspend) + wf_trav_kernel (dense waves walk the compacted ray queue, 64 VGPRs
-// -> 8 waves/SIMD to hide the walk's latency chain).  One pass = one launch of each.  Pixels are independent
-// (seeds depend on the pixel's own frame number), so they are allowed to drift apart: a segment with d deep
-// walks simply takes d + 1 passes.
-// ======================================================================================================
-// What a suspended pixel needs when its walk has been answered depends on where it stopped, so each of
-// the three suspension points has its own (small) record: 3 float4 while waiting for W1 (a fresh ray),
-// 6 (surface) / 11 (medium scatter) for W2, 5 / 8 for W3.  Everything else of SegCtx is at its initial
-// value or dead at that point; the tangent frame is rebuilt from its normal (header.cl:179-192 is pure).
-PT_DEV float4 pk(f3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
-PT_DEV float4 pku(f3 v, unsigned w) { return make_float4(v.x, v.y, v.z, prt_u2f(w)); }
-PT_DEV f3 xyz(float4 v) { return F3(v.x, v.y, v.z); }
-#define CTXP(j) wv.ctx[(size_t)(j) * wv.npix + id]
-PT_DEV unsigned ctx_bits(const SegCtx& c, bool w2_ran) {
-    return (c.e.sampledLobe & 0xffu) | ((unsigned)c.kind << 8) | (c.terminate ? 1u << 16 : 0u) | (c.surface ? 1u << 17 : 0u) |
-           (c.done ? 1u << 18 : 0u) | (c.sh ? 1u << 19 : 0u) | (w2_ran ? 1u << 20 : 0u);
-}
-PT_DEV void ctx_unbits(unsigned b, SegCtx& c, bool& w2_ran) {
-    c.e.sampledLobe = b & 0xffu; c.kind = (int)((b >> 8) & 0xffu);
-    c.terminate = (b >> 16) & 1u; c.surface = (b >> 17) & 1u; c.done = (b >> 18) & 1u; c.sh = (b >> 19) & 1u; w2_ran = (b >> 20) & 1u;
-}
-PT_DEV void ctx_store1(const DevWave& wv, size_t id, const SegCtx& c) {
-    CTXP(0) = pk(c.ray.origin, c.ray.time);
-    CTXP(1) = pku(c.ray.dir, c.rng.s0);
-    CTXP(2) = make_float4(prt_u2f(c.rng.s1), 0.f, 0.f, 0.f);
-}
-PT_DEV void ctx_load1(const DevWave& wv, size_t id, SegCtx& c) {
-    seg_ctx_init(c);
-    const float4 p0 = CTXP(0), p1 = CTXP(1), p2 = CTXP(2);
-    c.ray.origin = xyz(p0); c.ray.time = p0.w;
-    c.ray.dir = xyz(p1); c.rng.s0 = prt_f2u(p1.w); c.rng.s1 = prt_f2u(p2.x);
-    c.ray.normal = splat(0.0f); c.ray.pos = splat(0.0f); c.ray.t = 0.0f; c.ray.backside = false;
-}
-template <bool MEDIUM>
-PT_DEV void ctx_store2(const DevWave& wv, size_t id, const SegCtx& c, bool w2_ran) {
-    CTXP(0) = pk(c.ray.origin, c.ray.time);
-    CTXP(1) = pku(c.ray.dir, c.rng.s0);
-    CTXP(2) = pku(c.ray.normal, c.rng.s1);
-    CTXP(3) = pk(c.e.wi, c.e.pdf);
-    CTXP(4) = pku(c.e.weight, ctx_bits(c, w2_ran));
-    CTXP(5) = pku(c.e.frame.normal, (unsigned)(c.mesh_id + 1));
-    if (MEDIUM && c.kind == K_SCATTER) {
-        CTXP(6) = pk(c.ms_p, c.ps.pdf);
-        CTXP(7) = pk(c.ps.w, c.sh_tmax);
-        CTXP(8) = pk(c.ps.weight, c.ray.t);          // a scatter keeps the path ray's t (it becomes RTD.time)
-        CTXP(9) = pk(c.a_vis, 0.f);
-        CTXP(10) = pk(c.sh_d, 0.f);
-    }
-}
-template <bool MEDIUM>
-PT_DEV void ctx_load2(const DevWave& wv, size_t id, SegCtx& c, bool& w2_ran) {
-    seg_ctx_init(c);
-    const float4 p0 = CTXP(0), p1 = CTXP(1), p2 = CTXP(2), p3 = CTXP(3), p4 = CTXP(4), p5 = CTXP(5);
-    c.ray.origin = xyz(p0); c.ray.time = p0.w;
-    c.ray.dir = xyz(p1); c.rng.s0 = prt_f2u(p1.w);
-    c.ray.normal = xyz(p2); c.rng.s1 = prt_f2u(p2.w);
-    c.ray.pos = splat(0.0f); c.ray.t = 0.0f; c.ray.backside = false;
-    c.e.wi = xyz(p3); c.e.pdf = p3.w;
-    c.e.weight = xyz(p4); ctx_unbits(prt_f2u(p4.w), c, w2_ran);
-    c.e.frame = make_frame(xyz(p5)); c.mesh_id = (int)prt_f2u(p5.w) - 1;
-    if (MEDIUM && c.kind == K_SCATTER) {
-        const float4 p6 = CTXP(6), p7 = CTXP(7), p8 = CTXP(8), p9 = CTXP(9), p10 = CTXP(10);
-        c.ms_p = xyz(p6); c.ps.pdf = p6.w;
-        c.ps.w = xyz(p7); c.sh_tmax = p7.w;
-        c.ps.weight = xyz(p8); c.ray.t = p8.w;
-        c.a_vis = xyz(p9);
-        c.sh_d = xyz(p10); c.sh_o = c.ms_p;
-    }
-}
-template <bool MEDIUM>
-PT_DEV void ctx_store3(const DevWave& wv, size_t id, const SegCtx& c) {
-    CTXP(0) = pk(c.ray.origin, c.ray.time);
-    CTXP(1) = pk(c.ray.dir, c.ray.t);
-    CTXP(2) = pku(c.e.weight, ctx_bits(c, false));
-    CTXP(3) = pku(c.a, c.rng.s0);
-    CTXP(4) = pku((MEDIUM && c.kind == K_SCATTER) ? c.a_vis : c.b_vis, c.rng.s1);
-    if (MEDIUM && c.kind == K_SCATTER) {
-        CTXP(5) = pk(c.ms_p, c.alpha);
-        CTXP(6) = pk(c.ps.w, 0.f);
-        CTXP(7) = pk(c.ps.weight, 0.f);
-    }
-}
-template <bool MEDIUM>
-PT_DEV void ctx_load3(const DevWave& wv, size_t id, SegCtx& c) {
-    seg_ctx_init(c);
-    bool unused;
-    const float4 p0 = CTXP(0), p1 = CTXP(1), p2 = CTXP(2), p3 = CTXP(3), p4 = CTXP(4);
-    c.ray.origin = xyz(p0); c.ray.time = p0.w;
-    c.ray.dir = xyz(p1); c.ray.t = p1.w;
-    c.e.weight = xyz(p2); ctx_unbits(prt_f2u(p2.w), c, unused);
-    c.a = xyz(p3); c.rng.s0 = prt_f2u(p3.w);
-    c.rng.s1 = prt_f2u(p4.w);
-    if (MEDIUM && c.kind == K_SCATTER) {
-        c.a_vis = xyz(p4);
-        const float4 p5 = CTXP(5), p6 = CTXP(6), p7 = CTXP(7);
-        c.ms_p = xyz(p5);
-        c.ps.w = xyz(p6);
-        c.ps.weight = xyz(p7);
-    } else {
-        c.b_vis = xyz(p4);
-    }
-}
-#undef CTXP
-
-// does the walk of `rq` get past its first step?  (bvh.cl:144-157 at node 0 -- the same test the walk starts with)
-PT_DEV bool walk_is_deep(const DevScene& sc, const TravReq& rq) {
-    if (sc.root_is_leaf) return sc.root_leaf_count != 0;
-    Ray ray;
-    ray.origin = rq.o; ray.dir = rq.d;
-    const PairTest pt = test_pair(load_pair(sc.pairs, 0u), ray_pre(ray), rq.tmax);
-    return pt.go0 || pt.go1;
-}
-
-template <unsigned MATS, bool MEDIUM>
-#ifndef PT_SHADE_WAVES
-#define PT_SHADE_WAVES 4
-#endif
-__global__ __launch_bounds__(256, PT_SHADE_WAVES) void wf_shade_kernel(const DevScene sc, const DevCamera cam, const DevState S, const DevWave wv,
-                                                       const FrameArgs fa, float4* __restrict__ fb, const unsigned pass) {
-    constexpr int TILE_W = 16, WAVES_X = 2;
-    const int tiles_x = (fa.width + TILE_W - 1) / TILE_W;
-    const int tile_x = (int)(blockIdx.x % (unsigned)tiles_x), tile_y = (int)(blockIdx.x / (unsigned)tiles_x);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int lx = tile_x * TILE_W + (wave % WAVES_X) * 8 + (lane & 7);
-    const int ly = tile_y * 16 + (wave / WAVES_X) * 8 + (lane >> 3);
-    if (lx >= fa.width || ly >= fa.rows) return;
-    const size_t id = (size_t)ly * (size_t)fa.width + (size_t)lx;
-    const int gx = lx;
-    const int gy = fa.row0 + (ly / fa.block_rows * fa.n_parts + fa.part) * fa.block_rows + ly % fa.block_rows;
-
-    uint4 prog = wv.prog[id];
-    const uint4 e4 = S.q4[id];
-    bool active = prog.x < fa.n_frames;
-    if (active && prog.y == 0 && fa.spp_limit && (e4.w & 2u) && e4.x >= fa.spp_limit) active = false;     // frozen
-    bool enqueue = false;
-    TravReq rq;
-    rq.want = false; rq.o = rq.d = splat(0.0f); rq.tmax = PT_INF;
-    bool rq_any = false;
-    if (active) {
-        Path st;
-        {
-            const float4 a = S.q0[id], b = S.q1[id], c = S.q2[id], d = S.q3[id];
-            st.origin = F3(a.x, a.y, a.z); st.time = a.w;
-            st.dir = F3(b.x, b.y, b.z); st.dist = b.w;
-            st.mask = F3(c.x, c.y, c.z); st.total = prt_f2u(c.w);
-            st.acc[0] = d.x; st.acc[1] = d.y; st.acc[2] = d.z; st.acc[3] = d.w;
-            st.samples = e4.x;
-            st.diff = e4.y & 0xffffu; st.spec = e4.y >> 16;
-            st.trans = e4.z & 0xffffu; st.scatters = e4.z >> 16;
-            st.wasSpecular = (e4.w & 1u) != 0; st.reset = (e4.w & 2u) != 0;
-            const float4 h0 = wv.hc0[id], h1 = wv.hc1[id];
-            const unsigned hb = prt_f2u(h1.w);
-            st.hc.valid = (hb & 1u) != 0; st.hc.didHit = (hb & 2u) != 0; st.hc.backside = (hb & 4u) != 0;
-            st.hc.mesh_id = (int)(hb >> 8) - 1;
-            st.hc.t = h0.x; st.hc.normal = F3(h0.y, h0.z, h0.w); st.hc.pos = F3(h1.x, h1.y, h1.z);
-        }
-        SegCtx c;
-        TravRes res;
-        res.found = false; res.t = PT_INF; res.th.u = res.th.v = res.th.w = 0.0f; res.th.slot = 0;
-        bool w2_ran = false;
-        unsigned stage = prog.y;                                // 0 = segment boundary, k = the answer of W_k is in res0/res1
-        if (stage != 0) {
-            const float4 r = wv.res0[id];
-            const unsigned r1 = wv.res1[id];
-            res.found = (r1 >> 31) != 0; res.t = r.x; res.th.u = r.y; res.th.v = r.z; res.th.w = r.w; res.th.slot = r1 & 0x7fffffffu;
-            if (stage == 1) ctx_load1(wv, id, c);
-            else if (stage == 2) ctx_load2<MEDIUM>(wv, id, c, w2_ran);
-            else ctx_load3<MEDIUM>(wv, id, c);
-        }
-        // straight-line phases; `enqueue` = suspended at a walk that really enters the tree
-        auto trivial = [&](const TravReq& q) {                  // answer of a walk that is not needed / ends at its first step
-            res.found = false; res.t = q.tmax; res.th.u = res.th.v = res.th.w = 0.0f; res.th.slot = 0;
-        };
-        if (stage == 0) {
-            const unsigned f = prog.x;
-            rq = seg_begin(cam, c, st, gx, gy, fa.width, fa.full_height, fa.first_frame + f, fa.seed_pairs[2 * f], fa.seed_pairs[2 * f + 1]);
-            rq_any = false; stage = 1;
-            if (rq.want && walk_is_deep(sc, rq)) { enqueue = true; ctx_store1(wv, id, c); } else trivial(rq);
-        }
-        if (stage == 1 && !enqueue) {
-            rq = seg_after_w1<MATS, MEDIUM>(sc, c, st, res);
-            w2_ran = rq.want; rq_any = false; stage = 2;
-            if (rq.want && walk_is_deep(sc, rq)) { enqueue = true; ctx_store2<MEDIUM>(wv, id, c, w2_ran); } else trivial(rq);
-        }
-        if (stage == 2 && !enqueue) {
-            rq = seg_after_w2<MATS, MEDIUM>(sc, c, st, w2_ran, res);
-            rq_any = true; stage = 3;
-            if (rq.want && walk_is_deep(sc, rq)) { enqueue = true; ctx_store3<MEDIUM>(wv, id, c); } else trivial(rq);
-        }
-        bool finished_segment = false;
-        if (stage == 3 && !enqueue) {
-            seg_finish(sc, c, st, res.found);
-            finished_segment = true;
-        }
-        if (finished_segment) { prog.x += 1; prog.y = 0; }
-        else prog.y = stage;
-        // state back to HBM
-        S.q0[id] = make_float4(st.origin.x, st.origin.y, st.origin.z, st.time);
-        S.q1[id] = make_float4(st.dir.x, st.dir.y, st.dir.z, st.dist);
-        S.q2[id] = make_float4(st.mask.x, st.mask.y, st.mask.z, prt_u2f(st.total));
-        S.q3[id] = make_float4(st.acc[0], st.acc[1], st.acc[2], st.acc[3]);
-        const unsigned flags = (st.wasSpecular ? 1u : 0u) | (st.reset ? 2u : 0u);
-        S.q4[id] = make_uint4(st.samples, (st.diff & 0xffffu) | (st.spec << 16), (st.trans & 0xffffu) | (st.scatters << 16), flags);
-        wv.hc0[id] = make_float4(st.hc.t, st.hc.normal.x, st.hc.normal.y, st.hc.normal.z);
-        wv.hc1[id] = make_float4(st.hc.pos.x, st.hc.pos.y, st.hc.pos.z,
-                                 prt_u2f((st.hc.valid ? 1u : 0u) | (st.hc.didHit ? 2u : 0u) | (st.hc.backside ? 4u : 0u) | ((unsigned)(st.hc.mesh_id + 1) << 8)));
-        wv.prog[id] = prog;
-        if (finished_segment) {
-            const float ns = (float)st.samples;                    // write_imagef, main.cl:159
-            fb[id] = make_float4(st.acc[0] / ns, st.acc[1] / ns, st.acc[2] / ns, st.acc[3] / ns);
-            active = prog.x < fa.n_frames && !(fa.spp_limit && st.reset && st.samples >= fa.spp_limit);
-        }
-    }
-    // compact the suspended rays of this wave into the queue: ballot + one atomic per wave
-    const unsigned long long m = __ballot(enqueue);
-    if (m) {
-        unsigned base = 0;
-        const int leader = (int)__builtin_ctzll(m);
-        if (lane == leader) base = atomicAdd(&wv.qcount[pass & 1u], (unsigned)__popcll(m));
-        base = (unsigned)__builtin_amdgcn_readlane((int)base, leader);
-        if (enqueue) {
-            const unsigned idx = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-            wv.ray_o[idx] = make_float4(rq.o.x, rq.o.y, rq.o.z, rq.tmax);
-            wv.ray_d[idx] = make_float4(rq.d.x, rq.d.y, rq.d.z, prt_u2f((unsigned)id | (rq_any ? 0x80000000u : 0u)));
-        }
-    }
-    if (fa.unfinished) {
-        const unsigned long long u = __ballot(active);
-        if (u && lane == (int)__builtin_ctzll(u)) atomicAdd(fa.unfinished, (unsigned long long)__popcll(u));
-    }
-}
-
-#ifndef PT_TRAV_WAVES
-#define PT_TRAV_WAVES 8     // 64 VGPRs: the walk is a chain of dependent fetches, occupancy is what hides it
-#endif
-__global__ __launch_bounds__(256, PT_TRAV_WAVES) void wf_trav_kernel(const DevScene sc, const DevWave wv, const unsigned pass) {
-    extern __shared__ unsigned lds_stack[];                     // sc.stack_levels x 256
-    TravStack stk;
-    stk.lds = lds_stack + threadIdx.x; stk.stride = 256;
-    const unsigned n = wv.qcount[pass & 1u];
-    if (blockIdx.x == 0 && threadIdx.x == 0) wv.qcount[(pass + 1u) & 1u] = 0;       // next pass appends to the other counter
-    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-        const float4 a = wv.ray_o[i], b = wv.ray_d[i];
-        const unsigned ob = prt_f2u(b.w);
-        TravReq rq;
-        rq.want = true; rq.o = F3(a.x, a.y, a.z); rq.d = F3(b.x, b.y, b.z); rq.tmax = a.w;
-        const TravRes r = walk(sc, (ob >> 31) != 0, rq, stk);
-        const unsigned pix = ob & 0x7fffffffu;
-        wv.res0[pix] = make_float4(r.t, r.th.u, r.th.v, r.th.w);
-        wv.res1[pix] = r.th.slot | (r.found ? 0x80000000u : 0u);
     }
 }
 
@@ -509,11 +280,13 @@ __global__ void selftest_math_kernel(int fn, const float* __restrict__ a, const 
 template <unsigned MATS, bool MEDIUM, int WAVES>
 static void launch_variant_w(const DevScene& sc, const DevCamera& cam, const DevState& S, const FrameArgs& fa, float4* fb,
                              hipStream_t stream) {
-    constexpr unsigned TILE_H = PT_BLOCK >= 128 ? 16 : 8, TILE_W = PT_BLOCK / TILE_H;
-    const unsigned tiles_x = ((unsigned)fa.width + TILE_W - 1) / TILE_W, tiles_y = ((unsigned)fa.rows + TILE_H - 1) / TILE_H;
+    const unsigned tiles_x = ((unsigned)fa.width + 7u) / 8u, tiles_y = ((unsigned)fa.rows + 7u) / 8u;
     const size_t lds = (size_t)sc.stack_levels * PT_BLOCK * sizeof(unsigned);
-    if (lds > 65536u)        // only a 4-wave build with a tree that fills the reference's 64-entry stack to the brim
+    static size_t lds_attr = 0;                                  // per template instance
+    if (lds > 65536u && lds > lds_attr) {   // only a 4-wave build with a tree that fills the reference's 64-entry stack to the brim
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<MATS, MEDIUM, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        lds_attr = lds;
+    }
     const unsigned n_tiles = tiles_x * tiles_y;
     if (fa.tile_first >= n_tiles) return;
     const unsigned grid = (n_tiles - fa.tile_first + fa.tile_stride - 1) / fa.tile_stride;      // tiles of this sub-part
@@ -522,12 +295,14 @@ static void launch_variant_w(const DevScene& sc, const DevCamera& cam, const Dev
 template <unsigned MATS, bool MEDIUM>
 static void launch_variant(const DevScene& sc, const DevCamera& cam, const DevState& S, const FrameArgs& fa, float4* fb,
                            hipStream_t stream) {
-    const char* e_waves = std::getenv("PRT_WAVES");                       // 4 / 5: override (tests, experiments)
-    const int forced = e_waves ? std::atoi(e_waves) : 0;
+    static const int forced = [] { const char* e = std::getenv("PRT_WAVES"); return e ? std::atoi(e) : 0; }();   // 4 / 5: override (tests, experiments)
     // 5 waves where latency rules: the node records alone exceed one XCD's L2, or the scene raymarches SDFs (+11 %)
     const bool big = forced ? forced >= 5 : (sc.n_pairs > 65536u || sc.n_sdfs != 0u);
+#ifndef PT_DEV_ONE_VARIANT
     if (big) launch_variant_w<MATS, MEDIUM, 5>(sc, cam, S, fa, fb, stream);
-    else launch_variant_w<MATS, MEDIUM, PT_MIN_WAVES>(sc, cam, S, fa, fb, stream);
+    else
+#endif
+    launch_variant_w<MATS, MEDIUM, PT_MIN_WAVES>(sc, cam, S, fa, fb, stream);
 }
 
 // Variant choice = the AOT analogue of the reference's per-scene program build (include/CL/cl_kernel.h):
@@ -536,6 +311,11 @@ const char* launch_render(const DevScene& sc, const DevCamera& cam, const DevSta
                           hipStream_t stream) {
     constexpr unsigned LD = PRT_MAT_LIGHT | PRT_MAT_DIFF;
     const unsigned am = sc.active_mats;
+#ifdef PT_DEV_ONE_VARIANT                 // development builds (tools/): only the headline variant, compiles in seconds
+    if (sc.n_sdfs || sc.has_medium || am != LD) return nullptr;
+    launch_variant<LD, false>(sc, cam, S, fa, fb, stream);
+    return "render_kernel<LIGHT|DIFF>";
+#else
     if (sc.n_sdfs) {                      // H_SDF scenes: the generic variants that carry the raymarcher
         if (!sc.has_medium) { launch_variant<PT_MATS_SDF, false>(sc, cam, S, fa, fb, stream); return "render_kernel<generic,sdf>"; }
         launch_variant<PT_MATS_SDF, true>(sc, cam, S, fa, fb, stream);
@@ -549,36 +329,11 @@ const char* launch_render(const DevScene& sc, const DevCamera& cam, const DevSta
     if (am == LD) { launch_variant<LD, true>(sc, cam, S, fa, fb, stream); return "render_kernel<LIGHT|DIFF,medium>"; }
     launch_variant<0u, true>(sc, cam, S, fa, fb, stream);
     return "render_kernel<generic,medium>";
-}
-
-template <unsigned MATS, bool MEDIUM>
-static void launch_wf_variant(const DevScene& sc, const DevCamera& cam, const DevState& S, const DevWave& wv, const FrameArgs& fa,
-                              float4* fb, unsigned pass, hipStream_t stream) {
-    const unsigned tiles_x = ((unsigned)fa.width + 15u) / 16u, tiles_y = (unsigned)((fa.rows + 15) >> 4);
-    hipLaunchKernelGGL((wf_shade_kernel<MATS, MEDIUM>), dim3(tiles_x * tiles_y), dim3(256), 0, stream, sc, cam, S, wv, fa, fb, pass);
-}
-void launch_wf_pass(const DevScene& sc, const DevCamera& cam, const DevState& S, const DevWave& wv, const FrameArgs& fa, float4* fb,
-                    unsigned pass, unsigned trav_blocks, hipStream_t stream) {
-    constexpr unsigned LD = PRT_MAT_LIGHT | PRT_MAT_DIFF;
-    const unsigned am = sc.active_mats;
-    if (sc.n_sdfs) {
-        if (!sc.has_medium) launch_wf_variant<PT_MATS_SDF, false>(sc, cam, S, wv, fa, fb, pass, stream);
-        else launch_wf_variant<PT_MATS_SDF, true>(sc, cam, S, wv, fa, fb, pass, stream);
-    } else if (!sc.has_medium) {
-        if (am == LD) launch_wf_variant<LD, false>(sc, cam, S, wv, fa, fb, pass, stream);
-        else launch_wf_variant<0u, false>(sc, cam, S, wv, fa, fb, pass, stream);
-    } else {
-        if (am == LD) launch_wf_variant<LD, true>(sc, cam, S, wv, fa, fb, pass, stream);
-        else launch_wf_variant<0u, true>(sc, cam, S, wv, fa, fb, pass, stream);
-    }
-    const size_t lds = (size_t)sc.stack_levels * 256 * sizeof(unsigned);
-    if (lds > 65536u) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wf_trav_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(wf_trav_kernel, dim3(trav_blocks), dim3(256), lds, stream, sc, wv, pass);
+#endif
 }
 
 unsigned render_tile_count(int width, int rows) {
-    constexpr unsigned TILE_H = PT_BLOCK >= 128 ? 16 : 8, TILE_W = PT_BLOCK / TILE_H;
-    return (((unsigned)width + TILE_W - 1) / TILE_W) * (((unsigned)rows + TILE_H - 1) / TILE_H);
+    return (((unsigned)width + 7u) / 8u) * (((unsigned)rows + 7u) / 8u);
 }
 
 void make_dev_camera(const prt_camera& in, DevCamera& out) {

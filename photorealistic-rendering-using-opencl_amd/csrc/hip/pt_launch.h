@@ -11,9 +11,6 @@ namespace prt {
 // build, include/CL/cl_kernel.h); returns the variant's name for profiles/stats
 const char* launch_render(const DevScene& sc, const DevCamera& cam, const DevState& S, const FrameArgs& fa, float4* fb,
                           hipStream_t stream);
-// one wavefront pass: shade (resume / start, suspend at deep walks) + traverse the compacted queue
-void launch_wf_pass(const DevScene& sc, const DevCamera& cam, const DevState& S, const DevWave& wv, const FrameArgs& fa, float4* fb,
-                    unsigned pass, unsigned trav_blocks, hipStream_t stream);
 // workgroups (tiles) launch_render uses for a width x rows frame part
 unsigned render_tile_count(int width, int rows);
 // per-camera part of createCamRay (camera.cl:19-28), on the host with the arithmetic of pt_device.h

@@ -100,24 +100,6 @@ struct DevState {
     uint4* q4;    // samples, diff | spec << 16, trans | scatters << 16, was_specular | reset << 1
 };
 
-// Wavefront pipeline (pt_kernels.hip: wf_shade_kernel / wf_trav_kernel): what lives in HBM between passes
-// on top of DevState.  A pixel that reaches a BVH walk which really enters the tree is SUSPENDED: its
-// segment context goes to `ctx` (PRT_WF_CTX_PLANES float4 planes, SoA), its ray to the compacted queue
-// (ballot + one atomic per wave), and a lean traversal kernel answers into `res0/res1` by pixel.
-#define PRT_WF_CTX_PLANES 11
-struct DevWave {
-    float4* hc0;             // hit cache: t, normal.xyz
-    float4* hc1;             // hit cache: pos.xyz, bits(valid | didHit << 1 | backside << 2 | (mesh_id + 1) << 8)
-    uint4* prog;             // x = frames done in this call, y = phase (0 = at a segment boundary, 1..3 = waiting for W1..W3)
-    float4* ctx;             // [PRT_WF_CTX_PLANES][npix]
-    float4* ray_o;           // queue: origin.xyz, tmax
-    float4* ray_d;           // queue: dir.xyz, bits(pixel | any << 31)
-    float4* res0;            // by pixel: t, u, v, w
-    unsigned* res1;          // by pixel: slot | found << 31
-    unsigned* qcount;        // [2] queue length, double-buffered by pass parity
-    size_t npix;
-};
-
 struct FrameArgs {
     int width, full_height, row0, rows;     // tile of the image: `rows` local rows
     int block_rows, n_parts, part;          // local row ly -> global row row0 + (ly / B * n_parts + part) * B + ly % B
@@ -129,6 +111,7 @@ struct FrameArgs {
                                             // done}; the last wave of the launch writes the count here (pinned host memory) and
                                             // zeroes the pair for the next launch: no copy / fill kernels between launches
     uint32_t tile_first, tile_stride;       // this launch covers the tiles tile_first + k * tile_stride (sub-part of the frame)
+    uint32_t walk_min_lanes;                // lane machine: a walk phase of a wave ends once fewer lanes than this are still walking
 };
 
 }  // namespace prt

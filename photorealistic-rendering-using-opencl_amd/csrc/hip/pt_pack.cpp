@@ -1,0 +1,204 @@
+// pt_pack.cpp -- host side of prt_upload_scene: validates the reference-layout scene buffers (include/prt.h,
+// src/main.cpp:93-122,401-418) and re-packs them into the records of pt_layout.h.  Pure host code (no HIP call), so
+// a rejected scene leaves the context untouched and tests/emu can run the same packing without a device.
+#include "pt_pack.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <utility>
+
+namespace prt {
+
+static DevMaterial pack_material(const prt_material& m) {
+    DevMaterial d;
+    std::memset(&d, 0, sizeof(d));
+    for (int i = 0; i < 3; ++i) { d.color[i] = m.color[i]; d.eta[i] = m.eta[i]; d.k[i] = m.k[i]; }
+    d.roughness = m.roughness;
+    d.bits = (uint32_t)m.t | ((uint32_t)m.lobes << 16) | ((uint32_t)m.dist << 24);
+    return d;
+}
+
+int pack_scene(const prt_config& cfg, const prt_scene_desc* s, PackedScene& out, std::string& err) {
+    auto fail = [&err](int, int code, const char* msg) { err = msg; return code; };
+    const int c = 0;
+    if (!s) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: null scene");
+    const uint32_t n_sph = s->object_count[0], n_sdf = s->object_count[1], n_box = s->object_count[2], n_quad = s->object_count[3];
+    const uint32_t n_mesh = s->object_count[7];
+    if (n_box) return fail(c, PRT_ERR_UNSUPPORTED, "prt_upload_scene: box primitives never render in the reference (box.cl is dead code)");
+    if (n_sph + n_sdf + n_quad != n_mesh) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: object_count does not add up");
+    if (n_sdf && !(cfg.geom_flags & PRT_GEOM_SDF)) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: SDF meshes but the config has no H_SDF");
+    if (n_mesh && !s->meshes) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: meshes is null");
+    const uint32_t T = s->triangle_count, N = s->bvh_node_count;
+    if (T && (!s->vertices || !s->normals || !s->primitive_indices || !s->bvh_nodes || !N))
+        return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: triangle buffers incomplete");
+
+    // ---- primitives + materials
+    std::vector<DevSphere>& spheres = out.spheres;
+    std::vector<DevQuad>& quads = out.quads;
+    std::vector<DevSdf>& sdfs = out.sdfs;
+    std::vector<DevMaterial>& mats = out.mats;
+    spheres.assign(n_sph, DevSphere{}); quads.assign(n_quad, DevQuad{}); sdfs.assign(n_sdf, DevSdf{}); mats.assign(n_mesh + 2, DevMaterial{});
+    std::memset(mats.data(), 0, mats.size() * sizeof(DevMaterial));
+    for (uint32_t i = 0; i < n_mesh; ++i) {
+        const prt_mesh& m = s->meshes[i];
+        mats[1 + i] = pack_material(m.mat);
+        if (i < n_sph) {
+            if (!(m.t & PRT_GEOM_SPHERE)) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: mesh order/type mismatch (sphere expected)");
+            DevSphere& d = spheres[i];
+            d.pos[0] = m.pos[0]; d.pos[1] = m.pos[1]; d.pos[2] = m.pos[2]; d.radius = m.joker[0];
+        } else if (i < n_sph + n_sdf) {
+            if (!(m.t & PRT_GEOM_SDF)) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: mesh order/type mismatch (sdf expected)");
+            DevSdf& d = sdfs[i - n_sph];
+            d.pos[0] = m.pos[0]; d.pos[1] = m.pos[1]; d.pos[2] = m.pos[2]; d.type = m.t;
+            for (int k = 0; k < 4; ++k) d.params[k] = m.joker[k];
+        } else {
+            if (!(m.t & PRT_GEOM_QUAD)) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: mesh order/type mismatch (quad expected)");
+            DevQuad& d = quads[i - n_sph - n_sdf];
+            std::memset(&d, 0, sizeof(d));
+            for (int k = 0; k < 3; ++k) { d.base[k] = m.joker[k]; d.edge0[k] = m.joker[3 + k]; d.edge1[k] = m.joker[6 + k]; d.normal[k] = m.joker[9 + k]; }
+            d.area = m.joker[12];
+            // kernels/geometry/quad.cl:16 anchor = base - (edge0 + edge1) * 0.5f ; :26-27 dot(edge, edge)
+            for (int k = 0; k < 3; ++k) d.anchor[k] = d.base[k] - (d.edge0[k] + d.edge1[k]) * 0.5f;
+            d.e0e0 = d.edge0[0] * d.edge0[0] + d.edge0[1] * d.edge0[1] + d.edge0[2] * d.edge0[2];
+            d.e1e1 = d.edge1[0] * d.edge1[0] + d.edge1[1] * d.edge1[1] + d.edge1[2] * d.edge1[2];
+            // pt_device.h out_of_unit_range: half an ulp of 1.0 scaled by the divisor, NaN = "divide instead"
+            auto half_ulp = [](float c) { return (c >= 9.094947017729282e-13f && c <= 1099511627776.0f) ? c * 5.9604644775390625e-08f : std::nanf(""); };
+            d.u0 = half_ulp(d.e0e0); d.u1 = half_ulp(d.e1e1);
+        }
+    }
+    if (s->obj_material) mats[n_mesh + 1] = pack_material(*s->obj_material);
+
+    // ---- BVH: reference layout -> NodePair records (inner nodes only), DFS order
+    std::vector<NodePair>& pairs = out.pairs;
+    pairs.clear();
+    DevScene sc{};
+    sc.root_is_leaf = 1;
+    sc.stack_levels = 1;
+    if (T) {
+        const prt_bvh_node* nodes = s->bvh_nodes;
+        auto leaf_ok = [&](const prt_bvh_node& nd) { return (uint64_t)nd.first_child_or_primitive + nd.primitive_count <= T; };
+        if (nodes[0].is_leaf) {
+            if (!leaf_ok(nodes[0])) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: root leaf range out of bounds");
+            sc.root_leaf_first = nodes[0].first_child_or_primitive;
+            sc.root_leaf_count = nodes[0].primitive_count;
+        } else {
+            sc.root_is_leaf = 0;
+            std::vector<uint32_t> pair_of(N, 0xFFFFFFFFu);
+            // Order of the NodePair records in memory.  Breadth-first keeps the top of the tree (which every ray
+            // walks) contiguous; depth-first (pre-order, left child right behind its parent) gives deep walks through
+            // big trees better line / page locality.  PRT_PAIR_ORDER=bfs|dfs overrides the choice.
+            std::vector<uint32_t> order;
+            const char* e_order = std::getenv("PRT_PAIR_ORDER");
+            const bool dfs = e_order ? (std::strcmp(e_order, "dfs") == 0) : (N > 65536u);
+            order.reserve(N / 2 + 1);
+            if (!dfs) {
+                order.push_back(0);
+                pair_of[0] = 0;
+                for (size_t head = 0; head < order.size(); ++head) {
+                    const uint32_t n = order[head];
+                    const uint32_t fc = nodes[n].first_child_or_primitive;
+                    if ((uint64_t)fc + 1 >= N) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: BVH child index out of range");
+                    for (uint32_t ch = fc; ch <= fc + 1; ++ch) {
+                        if (nodes[ch].is_leaf) continue;
+                        if (pair_of[ch] != 0xFFFFFFFFu || order.size() >= N) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: BVH is not a tree");
+                        pair_of[ch] = (uint32_t)order.size();
+                        order.push_back(ch);
+                    }
+                }
+            } else {
+                std::vector<uint32_t> st{0};
+                while (!st.empty()) {
+                    const uint32_t n = st.back();
+                    st.pop_back();
+                    if (n >= N || pair_of[n] != 0xFFFFFFFFu || order.size() >= N) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: BVH is not a tree");
+                    pair_of[n] = (uint32_t)order.size();
+                    order.push_back(n);
+                    const uint32_t fc = nodes[n].first_child_or_primitive;
+                    if ((uint64_t)fc + 1 >= N) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: BVH child index out of range");
+                    if (!nodes[fc + 1].is_leaf) st.push_back(fc + 1);
+                    if (!nodes[fc].is_leaf) st.push_back(fc);
+                }
+            }
+            pairs.resize(order.size());
+            for (size_t k = 0; k < order.size(); ++k) {
+                const prt_bvh_node& nd = nodes[order[k]];
+                NodePair& p = pairs[k];
+                for (int ch = 0; ch < 2; ++ch) {
+                    const prt_bvh_node& cn = nodes[nd.first_child_or_primitive + ch];
+                    for (int j = 0; j < 6; ++j) p.b[6 * ch + j] = cn.bounds[j];
+                    if (cn.is_leaf) {
+                        if (!leaf_ok(cn)) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: leaf range out of bounds");
+                        if (cn.primitive_count == 0xFFFFFFFFu) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: bad leaf");
+                        p.meta[2 * ch] = cn.first_child_or_primitive;
+                        p.meta[2 * ch + 1] = cn.primitive_count;
+                    } else {
+                        p.meta[2 * ch] = pair_of[nd.first_child_or_primitive + ch];
+                        p.meta[2 * ch + 1] = 0xFFFFFFFFu;
+                    }
+                }
+            }
+            // Most entries a walk can hold: one push per pair with two inner children on the way down.
+            // The reference's stack has 64 entries (bvh.cl:131) and overflows silently beyond that.
+            uint32_t max_sp = 0;
+            std::vector<std::pair<uint32_t, uint32_t>> todo{{0u, 0u}};
+            while (!todo.empty()) {
+                const std::pair<uint32_t, uint32_t> it = todo.back();
+                todo.pop_back();
+                const NodePair& p = pairs[it.first];
+                const bool in0 = p.meta[1] == 0xFFFFFFFFu, in1 = p.meta[3] == 0xFFFFFFFFu;
+                const uint32_t sp = it.second + ((in0 && in1) ? 1u : 0u);
+                if (sp > max_sp) max_sp = sp;
+                if (in0) todo.push_back({p.meta[0], sp});
+                if (in1) todo.push_back({p.meta[2], sp});
+            }
+            if (max_sp > 64u) return fail(c, PRT_ERR_UNSUPPORTED, "prt_upload_scene: BVH needs more than the 64 traversal-stack entries of the reference (bvh.cl:131)");
+            sc.stack_levels = max_sp + 1;
+        }
+    } else {
+        sc.root_leaf_first = 0; sc.root_leaf_count = 0;        // "no OBJ" = empty leaf root
+    }
+    // ---- triangles in leaf-slot order
+    std::vector<TriGeom>& tg = out.tg;
+    std::vector<TriNrm>& tn = out.tn;
+    tg.assign(T, TriGeom{}); tn.assign(T, TriNrm{});
+    for (uint32_t i = 0; i < T; ++i) {
+        const uint32_t fv = (uint32_t)s->primitive_indices[i] * 3u;        // triangle.cl:7 (uint arithmetic)
+        if ((uint64_t)fv + 2 >= (uint64_t)T * 3) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: primitive index out of range");
+        const float* p0 = s->vertices + 4 * (size_t)fv;
+        const float* p1 = p0 + 4; const float* p2 = p0 + 8;
+        TriGeom& g = tg[i];
+        float e1[3], e2[3];
+        for (int k = 0; k < 3; ++k) { g.p0[k] = p0[k]; e1[k] = p0[k] - p1[k]; e2[k] = p2[k] - p0[k]; }   // triangle.cl:12-13
+        for (int k = 0; k < 3; ++k) { g.e1[k] = e1[k]; g.e2[k] = e2[k]; }
+        g.n[0] = e1[1] * e2[2] - e1[2] * e2[1];                                                       // triangle.cl:15
+        g.n[1] = e1[2] * e2[0] - e1[0] * e2[2];
+        g.n[2] = e1[0] * e2[1] - e1[1] * e2[0];
+        const float* n0 = s->normals + 4 * (size_t)fv;
+        for (int k = 0; k < 3; ++k) { tn[i].n0[k] = n0[k]; tn[i].n1[k] = n0[4 + k]; tn[i].n2[k] = n0[8 + k]; }
+        tn[i].n0[3] = tn[i].n1[3] = tn[i].n2[3] = 0.0f;
+    }
+
+    sc.n_pairs = (uint32_t)pairs.size();
+    sc.n_spheres = n_sph; sc.n_quads = n_quad; sc.quad_mesh_base = n_sph + n_sdf; sc.n_meshes = n_mesh; sc.n_sdfs = n_sdf;
+    sc.marching_steps = cfg.marching_steps; sc.shadow_marching_steps = cfg.shadow_marching_steps;
+    sc.light_sphere = sc.light_quad = 0xFFFFFFFFu; sc.light_mesh = 0;
+    if (cfg.light_count) {
+        const uint32_t li = cfg.light_indices[0];
+        if (li >= n_mesh) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: light index out of range");
+        sc.light_mesh = li;
+        if (li < n_sph) sc.light_sphere = li;
+        else if (li >= n_sph + n_sdf) sc.light_quad = li - n_sph - n_sdf;
+        // an SDF light cannot be sampled (kernels/geometry/geometry.cl:11-32 returns false): both stay unset
+    }
+    sc.active_mats = cfg.active_mats; sc.geom_flags = cfg.geom_flags;
+    sc.max_bounces = cfg.max_bounces; sc.max_diff_bounces = cfg.max_diff_bounces; sc.max_spec_bounces = cfg.max_spec_bounces;
+    sc.max_trans_bounces = cfg.max_trans_bounces; sc.max_scattering_events = cfg.max_scattering_events;
+    sc.has_medium = cfg.has_global_medium; sc.fog_abs_only = cfg.fog_abs_only; sc.alpha_testing = cfg.alpha_testing;
+    sc.phase_function = cfg.phase_function; sc.fog_sigma_s = cfg.fog_sigma_s; sc.fog_sigma_t = cfg.fog_sigma_t; sc.phase_g = cfg.phase_g;
+    sc.ntrans_mask = cfg.active_mats & (PRT_MAT_DIEL | PRT_MAT_ROUGH_DIEL);
+    out.sc = sc;
+    return PRT_OK;
+}
+
+}  // namespace prt

@@ -1,0 +1,27 @@
+// pt_pack.h -- reference-layout scene buffers -> the device records of pt_layout.h (host code, see pt_pack.cpp)
+#pragma once
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime.h>      // vector types of pt_layout.h
+
+#include "prt.h"
+#include "pt_layout.h"
+
+namespace prt {
+
+struct PackedScene {
+    std::vector<NodePair> pairs;
+    std::vector<TriGeom> tg;
+    std::vector<TriNrm> tn;
+    std::vector<DevSphere> spheres;
+    std::vector<DevQuad> quads;
+    std::vector<DevSdf> sdfs;
+    std::vector<DevMaterial> mats;
+    DevScene sc{};             // every scalar field; the pointers (and env) are filled in by whoever owns the memory
+};
+
+// PRT_OK, or the prt error code with its message in `err`.  Nothing outside `out` is touched.
+int pack_scene(const prt_config& cfg, const prt_scene_desc* s, PackedScene& out, std::string& err);
+
+}  // namespace prt

@@ -1,0 +1,76 @@
+"""CPU tests of the product's DEVICE code: csrc/hip/pt_device.h (the lane machine, BVH steps, BSDFs, media ...)
+compiled for the host and run by the wave emulator of tests/emu/pt_emu.cpp, against
+  * the golden fixtures produced by the reference build (tests/golden/*.npz), and
+  * oracle/pt_oracle.c on ragged sizes,
+bit for bit, under the kernel's default schedule and under RANDOM walk-phase lengths (lanes drift in frame number:
+which lanes walk together must not change a bit).  No GPU involved: code generation for gfx950 is what -m gpu checks."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ALPHA_VARIANTS, GOLDEN, ROOT, VARIANTS
+
+sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+
+
+@pytest.fixture(scope="module")
+def emu():
+    import emu_api
+    emu_api.lib()
+    return emu_api
+
+
+def _scene(prt, variant, W, H):
+    scene_json, phase, use_env = VARIANTS[variant]
+    scene = prt.HostScene(scene_json)
+    cfg = scene.config(alpha_testing=variant in ALPHA_VARIANTS)
+    cfg.phase_function = phase
+    return scene, cfg, prt.default_camera(W, H), (prt.make_sky(64, 32) if use_env else None)
+
+
+def _same(oracle, s0, i0, s1, i1, what):
+    bad = oracle.state_fields_equal(s0, s1.view(oracle.PATH_STATE_DTYPE))
+    assert not bad, "%s: path state differs in %s" % (what, bad)
+    assert oracle.images_equal(i0, i1), "%s: framebuffer differs" % what
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS))
+@pytest.mark.parametrize("sched", [(8, 0), (1, 0), (8, 12345)])
+def test_device_code_on_host_matches_reference_golden(prt, oracle, emu, variant, sched):
+    g = np.load(os.path.join(GOLDEN, variant + ".npz"))
+    W, H, frames = int(g["width"]), int(g["height"]), int(g["frames"])
+    scene, cfg, cam, env = _scene(prt, variant, W, H)
+    state, img = emu.render(oracle.PATH_STATE_DTYPE, cfg, scene.desc, cam, W, H, prt.seed_pairs(frames), env=env,
+                            walk_min_lanes=sched[0], sched_seed=sched[1])
+    gstate = np.ascontiguousarray(g["state"]).view(oracle.PATH_STATE_DTYPE).reshape(-1)
+    _same(oracle, gstate, g["image"], state, img, "%s schedule %s" % (variant, sched))
+
+
+def test_spp_mode_and_batches_on_host(prt, oracle, emu):
+    g = np.load(os.path.join(GOLDEN, "cornell_diffuse_spp.npz"))
+    W, H, maxf, spp = int(g["width"]), int(g["height"]), int(g["frames"]), int(g["spp"])
+    scene, cfg, cam, env = _scene(prt, "cornell_diffuse", W, H)
+    seeds = prt.seed_pairs(maxf)
+    # the "N spp" rule in launches of 32 frames, as prt_render_spp issues them, under a random schedule
+    state = img = None
+    for f in range(0, maxf, 32):
+        state, img = emu.render(oracle.PATH_STATE_DTYPE, cfg, scene.desc, cam, W, H, seeds[2 * f:2 * (f + 32)], first_frame=1 + f,
+                                state=state, img=img, spp_limit=spp, sched_seed=99 + f)
+    gstate = np.ascontiguousarray(g["state"]).view(oracle.PATH_STATE_DTYPE).reshape(-1)
+    _same(oracle, gstate, g["image"], state, img, "spp golden")
+
+
+@pytest.mark.parametrize("variant", ["cornell_mixed", "cornell_media_hg", "cornell_sdf"])
+def test_ragged_frame_and_row_blocks_on_host(prt, oracle, emu, variant):
+    W, H, frames = 45, 27, 64
+    scene, cfg, cam, env = _scene(prt, variant, W, H)
+    seeds = prt.seed_pairs(frames)
+    ostate, oimg = oracle.Restatement().render(cfg, scene.desc, cam, W, H, seeds, env=env, threads=8)
+    state, img = emu.render(oracle.PATH_STATE_DTYPE, cfg, scene.desc, cam, W, H, seeds, env=env, sched_seed=7)
+    _same(oracle, ostate, oimg, state, img, variant + " ragged")
+    blocks = (4, 3, 1)
+    bstate, bimg = emu.render(oracle.PATH_STATE_DTYPE, cfg, scene.desc, cam, W, H, seeds, env=env, sched_seed=8, blocks=blocks)
+    rows = [r for r in range(H) if (r // blocks[0]) % blocks[1] == blocks[2]]
+    assert oracle.images_equal(oimg[rows], bimg), "row blocks differ from the full frame"

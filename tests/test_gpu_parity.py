@@ -428,36 +428,38 @@ def test_dragon_standin_matches_oracle(prt, oracle):
 
 
 @pytest.mark.parametrize("variant", list(VARIANTS))
-def test_wavefront_pipeline_matches_golden_and_megakernel(prt, oracle, variant):
-    """the alternative pipeline (shading kernel + lean traversal kernel over a compacted ray queue, pixels
-    allowed to drift in frame number) must give the same bits as the megakernel and the reference golden"""
+@pytest.mark.parametrize("min_lanes", [1, 64])
+def test_schedule_independence(prt, oracle, variant, min_lanes):
+    """the lane machine lets pixels drift in frame number; WHEN a wave ends its walk phases (prt_set_walk_min_lanes:
+    1 = every walk runs to its end, the lock-step schedule; 64 = a phase ends as soon as one lane is done, the most
+    drift) must not change a bit: same state and image as the reference golden, and a render continued under the
+    other schedule equals one rendered in one go"""
     g = np.load(os.path.join(GOLDEN, variant + ".npz"))
     W, H, frames = int(g["width"]), int(g["height"]), int(g["frames"])
     scene, cfg, cam, env, r = _setup(prt, variant, W, H)
-    r.set_pipeline("wavefront")
+    r.set_walk_min_lanes(min_lanes)
     r.render_frames(prt.seed_pairs(frames))
     gstate = np.ascontiguousarray(g["state"]).view(oracle.PATH_STATE_DTYPE).reshape(-1)
-    _assert_same(oracle, gstate, g["image"], r.read_state(), r.read_framebuffer(), variant + " wavefront vs golden")
-    # continue in the OTHER pipeline from the same state: the state is pipeline-independent
+    _assert_same(oracle, gstate, g["image"], r.read_state(), r.read_framebuffer(), "%s min_lanes %d vs golden" % (variant, min_lanes))
     more = prt.seed_pairs(frames + 20)[2 * frames:]
-    r.set_pipeline("mega")
+    r.set_walk_min_lanes(65 - min_lanes)
     r.render_frames(more, first_frame=frames + 1)
     s_mix, i_mix = r.read_state(), r.read_framebuffer()
     r.close()
     scene, cfg, cam, env, r2 = _setup(prt, variant, W, H)
     r2.render_frames(prt.seed_pairs(frames + 20))
-    _assert_same(oracle, r2.read_state().view(oracle.PATH_STATE_DTYPE), r2.read_framebuffer(), s_mix, i_mix, variant + " wavefront+mega vs mega")
+    _assert_same(oracle, r2.read_state().view(oracle.PATH_STATE_DTYPE), r2.read_framebuffer(), s_mix, i_mix, variant + " mixed schedules vs default")
     r2.close()
 
 
-def test_wavefront_spp_mode(prt, oracle):
+def test_spp_mode_lockstep_schedule(prt, oracle):
     g = np.load(os.path.join(GOLDEN, "cornell_diffuse_spp.npz"))
     W, H, maxf, spp = int(g["width"]), int(g["height"]), int(g["frames"]), int(g["spp"])
     scene, cfg, cam, env, r = _setup(prt, "cornell_diffuse", W, H)
-    r.set_pipeline(1)
+    r.set_walk_min_lanes(1)
     r.render_spp(spp, prt.seed_pairs(maxf))
     gstate = np.ascontiguousarray(g["state"]).view(oracle.PATH_STATE_DTYPE).reshape(-1)
-    _assert_same(oracle, gstate, g["image"], r.read_state(), r.read_framebuffer(), "wavefront spp golden")
+    _assert_same(oracle, gstate, g["image"], r.read_state(), r.read_framebuffer(), "lock-step spp golden")
     r.close()
 
 
