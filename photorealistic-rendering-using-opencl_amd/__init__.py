@@ -22,7 +22,7 @@ REPO = os.path.dirname(HERE)
 SCENES_DIR = os.path.join(REPO, "scenes")
 MODELS_DIR = os.path.join(SCENES_DIR, "models")
 
-__all__ = ["ensure_dragon_standin", "HostScene", "Renderer", "default_camera", "orbit_camera", "seed_pairs", "make_sky", "PrtError",
+__all__ = ["ensure_dragon_standin", "HostScene", "Renderer", "default_camera", "orbit_camera", "seed_pairs", "make_sky", "load_hdr", "PrtError",
            "Camera", "Config", "SceneDesc", "Stats", "PATH_STATE_DTYPE", "SCENES_DIR", "MODELS_DIR", "build"]
 
 
@@ -128,6 +128,21 @@ def make_sky(width=1024, height=512):
     return out
 
 
+def load_hdr(path):
+    """loadHDR of the reference (include/Texture/texture.h:31-39): a Radiance .hdr file -> float32 [h, w, 3]"""
+    lib = load_library()
+    w, h = C.c_int(0), C.c_int(0)
+    data = C.POINTER(C.c_float)()
+    err = C.create_string_buffer(256)
+    handle = lib.prth_hdr_load(os.fsencode(path), C.byref(w), C.byref(h), C.byref(data), err, 256)
+    if not handle:
+        raise PrtError("load_hdr: %s" % err.value.decode())
+    try:
+        return np.ctypeslib.as_array(data, shape=(h.value, w.value, 3)).copy()
+    finally:
+        lib.prth_hdr_free(handle)
+
+
 class Renderer:
     """One prt context (one HIP device).  Method names follow the C ABI one to one."""
 
@@ -182,9 +197,6 @@ class Renderer:
         self._chk(self.lib.prt_render_spp(self.ctx, spp, len(seeds) // 2, seeds.ctypes.data_as(C.c_void_p), C.byref(used)),
                   "prt_render_spp")
         return used.value
-
-    def set_walk_min_lanes(self, lanes):
-        self._chk(self.lib.prt_set_walk_min_lanes(self.ctx, int(lanes)), "prt_set_walk_min_lanes")
 
     def synchronize(self):
         self._chk(self.lib.prt_synchronize(self.ctx), "prt_synchronize")

@@ -82,7 +82,6 @@ PRT_API = [
     ("prt_reset", C.c_int, [C.c_void_p]),
     ("prt_render_frames", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     ("prt_render_spp", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]),
-    ("prt_set_walk_min_lanes", C.c_int, [C.c_void_p, C.c_uint32]),
     ("prt_synchronize", C.c_int, [C.c_void_p]),
     ("prt_read_framebuffer", C.c_int, [C.c_void_p, C.c_void_p]),
     ("prt_tonemap_rgba8", C.c_int, [C.c_void_p, C.c_void_p]),
@@ -111,6 +110,8 @@ PRTH_API = [
     ("prth_seed_pairs", C.c_int, [C.c_uint32, C.c_uint32, C.c_void_p]),
     ("prth_convert_model", C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]),
     ("prth_make_sky", C.c_int, [C.c_int, C.c_int, C.c_void_p]),
+    ("prth_hdr_load", C.c_void_p, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_float)), C.c_char_p, C.c_int]),
+    ("prth_hdr_free", None, [C.c_void_p]),
 ]
 
 _lib = None

@@ -17,7 +17,7 @@ HOSTCXX = os.environ.get("CXX", "g++")
 COMMON = ["-std=c++17", "-O3", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall",
           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(CSRC, "host"), "-I" + os.path.join(CSRC, "hip")]
 
-HOST_SOURCES = ["host/scene.cpp", "host/camera.cpp", "host/model_loader.cpp", "host/bvh.cpp", "host/host_capi.cpp"]
+HOST_SOURCES = ["host/scene.cpp", "host/camera.cpp", "host/model_loader.cpp", "host/bvh.cpp", "host/hdr_loader.cpp", "host/host_capi.cpp"]
 HIP_SOURCES = ["hip/prt_api.cpp", "hip/pt_pack.cpp", "hip/pt_kernels.hip"]
 
 

@@ -1,4 +1,5 @@
 #include "host_capi.h"
+#include "hdr_loader.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -122,6 +123,20 @@ extern "C" int prth_convert_model(const char* in_path, const char* out_path, cha
     if (!ml.SaveSoup(out_path)) { set_err(err, err_len, "cannot write soup"); return PRT_ERR_INVALID_ARGUMENT; }
     return PRT_OK;
 }
+
+extern "C" void* prth_hdr_load(const char* path, int* width, int* height, const float** rgb, char* err, int err_len) {
+    auto* v = new std::vector<float>();
+    std::string e;
+    int w = 0, h = 0;
+    if (!path || !width || !height || !rgb || !prt::IO::load_hdr(path, *v, w, h, e)) {
+        if (err && err_len > 0) { std::strncpy(err, (path ? e : std::string("null argument")).c_str(), (size_t)err_len - 1); err[err_len - 1] = 0; }
+        delete v;
+        return nullptr;
+    }
+    *width = w; *height = h; *rgb = v->data();
+    return v;
+}
+extern "C" void prth_hdr_free(void* handle) { delete static_cast<std::vector<float>*>(handle); }
 
 extern "C" int prth_make_sky(int w, int h, float* rgb) {
     if (!rgb || w <= 0 || h <= 0) return PRT_ERR_INVALID_ARGUMENT;

@@ -41,6 +41,10 @@ int prth_convert_model(const char* in_path, const char* out_soup_path, char* err
 /* deterministic procedural sky used as the HDR environment stand-in (no .hdr ships with the
  * reference): width x height RGB float, row 0 = top (v = 0) */
 int prth_make_sky(int width, int height, float* rgb);
+/* loadHDR (include/Texture/texture.h:31-39): a Radiance .hdr file as width x height x 3 floats, rows in file order.
+ * Returns a handle (prth_hdr_free) or NULL with the reason in err. */
+void* prth_hdr_load(const char* path, int* width, int* height, const float** rgb, char* err, int err_len);
+void prth_hdr_free(void* handle);
 
 #ifdef __cplusplus
 }

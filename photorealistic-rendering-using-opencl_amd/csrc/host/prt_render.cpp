@@ -141,6 +141,15 @@ int main(int argc, char** argv) {
             std::vector<float> sky((size_t)1024 * 512 * 3);
             prth_make_sky(1024, 512, sky.data());
             CHECK(prt_upload_envmap(ctx, sky.data(), 1024, 512));
+        } else if (!env_map_filepath.empty()) {                    // loadHDR, include/GL/cl_gl_interop.h:77-80
+            char herr[256] = "";
+            int ew = 0, eh = 0;
+            const float* erg = nullptr;
+            void* hdr = prth_hdr_load(env_map_filepath.c_str(), &ew, &eh, &erg, herr, sizeof(herr));
+            if (!hdr) { std::fprintf(stderr, "-hdr: %s\n", herr); prt_destroy(ctx); return 1; }
+            const int rc_env = prt_upload_envmap(ctx, erg, ew, eh);
+            prth_hdr_free(hdr);
+            CHECK(rc_env);
         }
         CHECK(prt_resize(ctx, window_width, window_height));       // cl_flattenI, :451
 

@@ -1,0 +1,111 @@
+"""`-hdr <file>`: the Radiance RGBE reader (csrc/host/hdr_loader.cpp) that replaces the reference's loadHDR
+(include/Texture/texture.h:31-39 -> stbi_loadf).  Expected values are computed here from the format definition:
+pixel = mantissa * 2^(exponent - 136), exponent byte 0 = black; rows in file order; 3 floats per pixel."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _expected(rgbe):
+    e = rgbe[..., 3].astype(np.int32)
+    f = np.where(e == 0, 0.0, np.ldexp(1.0, e - 136)).astype(np.float32)
+    return (rgbe[..., :3].astype(np.float32) * f[..., None]).astype(np.float32)
+
+
+def _header(w, h, sig=b"#?RADIANCE", fmt=b"FORMAT=32-bit_rle_rgbe", res=None):
+    return sig + b"\n# made by tests/test_hdr.py\n" + fmt + b"\nEXPOSURE=1.0\n\n" + (res or b"-Y %d +X %d" % (h, w)) + b"\n"
+
+
+def _rle_channel(row):
+    """new-style RLE of one channel of one scanline: runs of >= 3 equal bytes as runs, the rest as literals"""
+    out = bytearray()
+    i, n = 0, len(row)
+    while i < n:
+        j = i
+        while j < n and j - i < 127 and row[j] == row[i]:
+            j += 1
+        if j - i >= 3:
+            out += bytes([128 + (j - i), row[i]])
+            i = j
+            continue
+        k = i
+        while k < n and k - i < 128 and not (k + 2 < n and row[k] == row[k + 1] == row[k + 2]):
+            k += 1
+        out += bytes([k - i]) + bytes(row[i:k])
+        i = k
+    return bytes(out)
+
+
+def _write(path, data):
+    with open(path, "wb") as f:
+        f.write(data)
+
+
+def test_flat_file(prt, tmp_path):
+    rng = np.random.default_rng(1)
+    w, h = 5, 3                                   # width < 8: always flat
+    rgbe = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    rgbe[0, 0, 3] = 0                             # a black pixel
+    p = str(tmp_path / "flat.hdr")
+    _write(p, _header(w, h) + rgbe.tobytes())
+    img = prt.load_hdr(p)
+    assert img.shape == (h, w, 3) and np.array_equal(img.view(np.uint32), _expected(rgbe).view(np.uint32))
+
+
+@pytest.mark.parametrize("sig", [b"#?RADIANCE", b"#?RGBE"])
+def test_rle_file(prt, tmp_path, sig):
+    rng = np.random.default_rng(2)
+    w, h = 37, 6
+    rgbe = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    rgbe[:, 5:20, 3] = 130                        # long runs in the exponent channel
+    rgbe[2, :, 0] = 7                             # a whole-scanline run
+    rgbe[1, 3, 3] = 0
+    body = b""
+    for j in range(h):
+        body += bytes([2, 2, w >> 8, w & 255])
+        for ch in range(4):
+            body += _rle_channel(rgbe[j, :, ch].tolist())
+    p = str(tmp_path / "rle.hdr")
+    _write(p, _header(w, h, sig=sig) + body)
+    img = prt.load_hdr(p)
+    assert np.array_equal(img.view(np.uint32), _expected(rgbe).view(np.uint32))
+    # the same pixels stored flat in a file wide enough for RLE: the decoder must notice the missing 2,2 marker
+    rgbe2 = rgbe.copy()
+    rgbe2[0, 0, 0] = 9                            # first byte != 2
+    p2 = str(tmp_path / "flat_wide.hdr")
+    _write(p2, _header(w, h) + rgbe2.tobytes())
+    assert np.array_equal(prt.load_hdr(p2).view(np.uint32), _expected(rgbe2).view(np.uint32))
+
+
+def test_bad_files_are_errors(prt, tmp_path):
+    w, h = 16, 2
+    good = _header(w, h) + bytes(w * h * 4)
+    cases = {
+        "nosig.hdr": good.replace(b"#?RADIANCE", b"#?RADIANCX"),
+        "fmt.hdr": _header(w, h, fmt=b"FORMAT=32-bit_rle_xyze") + bytes(w * h * 4),
+        "orient.hdr": _header(w, h, res=b"+Y 2 +X 16") + bytes(w * h * 4),
+        "trunc.hdr": _header(w, h) + bytes([1] * 7),
+        "badrle.hdr": _header(w, h) + bytes([2, 2, 0, 16, 200, 1]) + bytes(64),     # a run longer than the scanline
+    }
+    for name, data in cases.items():
+        p = str(tmp_path / name)
+        _write(p, data)
+        with pytest.raises(prt.PrtError):
+            prt.load_hdr(p)
+    with pytest.raises(prt.PrtError):
+        prt.load_hdr(str(tmp_path / "does_not_exist.hdr"))
+
+
+def test_cli_refuses_unreadable_hdr(prt, tmp_path):
+    """prt_render -hdr <missing file> must fail before rendering (the reference would print and die in stbi);
+    never a silent black sky.  No GPU needed: the file is read before the device is touched... the context is created
+    first, so on a box without a GPU the failure is the missing device -- either way a non-zero exit."""
+    exe = os.path.join(ROOT, "photorealistic-rendering-using-opencl_amd", "prt_render")
+    r = subprocess.run([exe, "-scene", os.path.join(ROOT, "scenes", "cornell_diffuse.json"), "-models", os.path.join(ROOT, "scenes", "models") + "/",
+                        "-hdr", str(tmp_path / "missing.hdr"), "-width", "16", "-height", "16", "-spp", "1", "-out", str(tmp_path / "o.pfm")],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode != 0

@@ -1,0 +1,14 @@
+#!/bin/bash
+# development helper: tools/build_variant.sh <name> [hipcc flags...]  ->  <package>/variants/libprt_<name>.so
+# (same sources as libprt.so with extra -D flags; picked up by tools/ab_builds.sh / ab_lib_env.sh through PRT_LIB)
+set -e
+name=$1; shift
+P="$(cd "$(dirname "$0")/.." && pwd)/photorealistic-rendering-using-opencl_amd"
+O=/tmp/prt_variant_$name; mkdir -p $O $P/variants
+COMMON="-std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-math -I$P/../include -I$P/csrc/host -I$P/csrc/hip"
+for s in prt_api.cpp pt_pack.cpp pt_kernels.hip; do
+  /opt/rocm/bin/hipcc $COMMON -x hip --offload-arch=gfx950 "$@" -c $P/csrc/hip/$s -o $O/$s.o &
+done
+wait
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $P/variants/libprt_$name.so $O/*.o $P/build/host_*.o
+echo $P/variants/libprt_$name.so
