@@ -163,13 +163,17 @@ __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene 
                 if (!off && lane_runnable(fa, L)) lane_front<MATS, MEDIUM>(sc, cam, fa, L, gx, gy);
                 if (!__any(L.stage == ST_BACK)) break;          // BSDF sampling failed under MIS (no probe, base.cl:168-172): rare
             }
-            if (L.stage == ST_WALKC && L.fresh) {               // the step at the root, dense; deeper rays go to the pool
+            {                                                   // the step at the root, dense; deeper rays go to the pool
+                const bool fresh = L.stage == ST_WALKC && L.fresh;
                 const Ray wr = lane_closest_ray<MEDIUM>(L);
-                const RayPre p = ray_pre(wr);
-                walk_begin(sc, false, wr, PT_INF, p, L.w, stk);
-                L.fresh = false;
-                const bool deep = !L.w.done;
-                const unsigned long long m = __ballot(deep);
+                bool deep = false;
+                if (fresh) {
+                    const RayPre p = ray_pre(wr);
+                    walk_begin(sc, false, wr, PT_INF, p, L.w, stk);
+                    L.fresh = false;
+                    deep = !L.w.done;
+                }
+                const unsigned long long m = __ballot(deep);   // every lane of the wave is here: pool_n stays wave-uniform
                 if (deep) {
                     const unsigned idx = pool_n + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
                     PoolEntry e;
