@@ -198,6 +198,9 @@ class Renderer:
                   "prt_render_spp")
         return used.value
 
+    def set_walk_min_lanes(self, lanes):
+        self._chk(self.lib.prt_set_walk_min_lanes(self.ctx, int(lanes)), "prt_set_walk_min_lanes")
+
     def synchronize(self):
         self._chk(self.lib.prt_synchronize(self.ctx), "prt_synchronize")
 

@@ -82,6 +82,7 @@ PRT_API = [
     ("prt_reset", C.c_int, [C.c_void_p]),
     ("prt_render_frames", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     ("prt_render_spp", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]),
+    ("prt_set_walk_min_lanes", C.c_int, [C.c_void_p, C.c_uint32]),
     ("prt_synchronize", C.c_int, [C.c_void_p]),
     ("prt_read_framebuffer", C.c_int, [C.c_void_p, C.c_void_p]),
     ("prt_tonemap_rgba8", C.c_int, [C.c_void_p, C.c_void_p]),

@@ -52,6 +52,7 @@ struct prt_ctx {
     hipEvent_t sub_ev0[MAX_SUB][2] = {};          // its start (prt_render_spp times every launch)
     hipEvent_t fork_ev = nullptr;
     unsigned long long* h_unfinished = nullptr;   // pinned, [MAX_SUB][2]: written by the last wave of a launch
+    uint32_t walk_min_lanes = 4;                   // FrameArgs::walk_min_lanes (prt_set_walk_min_lanes, PRT_WALK_MIN_LANES)
     prt_stats stats{};
     std::string err;
     const char* variant = "";
@@ -111,6 +112,7 @@ extern "C" int prt_create(int device, const prt_config* cfg, prt_ctx** out) {
             return PRT_ERR_HIP;
         }
     c->stream = c->own_stream;
+    if (const char* ev = std::getenv("PRT_WALK_MIN_LANES")) { const int k = std::atoi(ev); if (k >= 1 && k <= 64) c->walk_min_lanes = (uint32_t)k; }
     *out = c;
     return PRT_OK;
 }
@@ -319,6 +321,7 @@ static FrameArgs frame_args(prt_ctx* c, uint32_t first_frame, uint32_t n, const 
     fa.unfinished = count ? c->d_counters : nullptr;
     fa.unfinished_host = nullptr;
     fa.tile_first = 0; fa.tile_stride = 1;
+    fa.walk_min_lanes = c->walk_min_lanes;
     return fa;
 }
 
@@ -422,7 +425,7 @@ extern "C" int prt_render_spp(prt_ctx* c, uint32_t spp, uint32_t max_frames, con
         bool exhausted = false;
         // launches queued per sub-part: 1 (the other sub-part's kernel covers the host round trip; 2 measured the same)
         static const unsigned depth = [] { const char* e = std::getenv("PRT_QUEUE_DEPTH"); return (e && std::atoi(e) == 2) ? 2u : 1u; }();
-        const unsigned n_tiles = render_group_count(c->sc, c->width, c->rows);
+        const unsigned n_tiles = render_tile_count(c->width, c->rows);
         for (int j = 0; j < K; ++j) stop[j] = (unsigned)j >= n_tiles;      // a sub-part without tiles has nothing to do
         for (;;) {
             bool progressed = false, busy = false;
@@ -478,6 +481,13 @@ extern "C" int prt_render_spp(prt_ctx* c, uint32_t spp, uint32_t max_frames, con
     c->stats.frames = f;
     if (frames_used) *frames_used = f;
     if (unfinished) return fail(c, PRT_ERR_NOT_READY, "prt_render_spp: max_frames reached before every pixel finished");
+    return PRT_OK;
+}
+
+extern "C" int prt_set_walk_min_lanes(prt_ctx* c, uint32_t lanes) {
+    CTX_CHECK(c);
+    if (lanes < 1 || lanes > 64) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_set_walk_min_lanes: 1..64");
+    c->walk_min_lanes = lanes;
     return PRT_OK;
 }
 

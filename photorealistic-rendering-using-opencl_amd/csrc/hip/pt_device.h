@@ -283,9 +283,9 @@ struct TravRes { bool found; float t; TriHit th; };
 // both children's boxes are tested against the CURRENT best t before either leaf is tested; leaf children are tested
 // immediately, left first; of two inner children the nearer (by entry distance, ties -> left) is followed and the
 // other pushed.  Real branches (scalar mask work, free next to the vector pipe) rather than selects: the shape with
-// the fewest vector instructions per step.  render_kernel takes the root step inside a pixel's shading pass and hands
-// {node, far child} of the rays that go deeper to the wave's batch walk.  found: (closest) a triangle was accepted,
-// (any) a triangle closer than tmax exists.
+// the fewest vector instructions per step.  The lane machine (lane_kernel) runs a wave's walks for a bounded number of
+// steps; a lane whose ray needs more keeps {node, sp, t, hit} for the wave's next walk phase, the LDS stack column
+// stays the lane's own.  found: (closest) a triangle was accepted, (any) a triangle closer than tmax exists.
 struct WalkState { unsigned node, sp; float t; TriHit th; bool found, done; };
 
 PT_DEV void walk_begin(const DevScene& sc, const bool ANY_HIT, const Ray& ray, const float tmax, const RayPre& p, WalkState& w,
@@ -1069,25 +1069,27 @@ PT_DEV f3 env_lookup(const DevScene& sc, f3 dir) {
 PT_DEV float power_heuristic(float pdf0, float pdf1) { return (pdf0 * pdf0) / (pdf0 * pdf0 + pdf1 * pdf1); }
 
 // ---- per-pixel state in registers: the lane machine ------------------------------------------------------------
-// One lane owns K pixels (render_kernel, pt_kernels.hip) and advances each of them segment by segment (one segment = one
-// launch of the reference's render_kernel for that pixel, kernels/main.cl:66-163 -> integrators/pathtracing.cl:4-120 +
-// base.cl:31-260) as a small state machine.  One PASS over a pixel runs, in this order,
-//   lane_closest_done      the closest-hit walk the pixel was waiting for is answered: the rest of intersect_scene
-//                          (intersect.cl:167-236), result into Lane::h
-//   lane_back              after a probe: MIS term of the probe, light sampling (lightSample base.cl:79-134 / the probe
-//                          part of volumePhaseSample), the shadow ray's primitive tests; may ask for W3 = the any-hit
-//                          walk of the shadow ray, which runs right there
-//   lane_finish            radiance into acc, Russian roulette, bounce caps (pathtracing.cl:93-118, main.cl:142)
-//   lane_front             seeds + path (re)start (main.cl:108-136) once per segment; then either ask for W1 =
-//                          intersect_scene of the path ray (pathtracing.cl:27) when no cached hit exists (fresh camera
-//                          ray, continuation of a specular bounce), or -- with the hit in hand -- the medium event /
-//                          miss / emitter / BSDF or phase sampling of the segment; lanes that need no probe finish their
-//                          segment right here, the others ask for W2 = intersect_scene of the BSDF-sampled probe ray
-//                          (bsdfSample, base.cl:54-57) or of the phase-sampled one (base.cl:247)
-//   walk_begin             the step at the root of W1 / W2; a ray that goes deeper is handed to the wave's batch walk
-// and the pixel is parked (lane_pack) until its next pass.  A pixel whose segment needs W1 and W2 (a path restart) takes
-// two passes for it and falls behind its neighbours in frame number -- legal because pixels are independent: the seeds
-// are a function of the lane's own frame number (main.cl:108-109).
+// One lane owns one pixel and advances it segment by segment (one segment = one launch of the reference's
+// render_kernel for that pixel, kernels/main.cl:66-163 -> integrators/pathtracing.cl:4-120 + base.cl:31-260), as a
+// small state machine, so that a wave never waits for its deepest BVH walk.  One ITERATION of the wave runs, in order,
+//   A  lane_front          READY lanes: seeds + path (re)start (main.cl:108-136) once per segment; then either ask for
+//                          W1 = intersect_scene of the path ray (pathtracing.cl:27) when no cached hit exists (fresh
+//                          camera ray, continuation of a specular bounce), or -- with the hit in hand -- the medium
+//                          event / miss / emitter / BSDF or phase sampling of the segment; lanes that need no probe
+//                          finish their segment right here, the others ask for W2 = intersect_scene of the BSDF-sampled
+//                          probe ray (bsdfSample, base.cl:54-57) or of the phase-sampled one (base.cl:247)
+//   B  closest-hit walk    every lane with a W1 / W2 in flight steps through the tree; the phase ends when fewer than
+//                          FrameArgs::walk_min_lanes lanes are still walking and somebody has finished.  Unfinished
+//                          lanes keep their WalkState and go on in the next iteration's B; a finished lane runs
+//                          lane_closest_done (the rest of intersect_scene; result into Lane::h)
+//   C  lane_back           lanes whose probe is answered: MIS term of the probe, light sampling (lightSample base.cl:
+//                          79-134 / the probe part of volumePhaseSample), may ask for W3 = shadow ray (any hit)
+//   D  any-hit walk        as B, for the shadow rays
+//   E  lane_finish         radiance into acc, Russian roulette, bounce caps (pathtracing.cl:93-118, main.cl:142)
+// A lane with shallow rays completes one segment per iteration; a lane with a deep ray sits out A/C/E until its walk
+// is done and falls behind in frame number -- legal because pixels are independent: the seeds are a function of the
+// lane's own frame number (main.cl:108-109).  Which lanes walk together changes nothing a lane computes: results are
+// schedule-independent (tests/test_emu.py runs these same functions on the host with random phase lengths).
 //
 // Exact shortcuts relative to the reference's segment (each removes work, none changes a bit):
 //   * hit cache: the reference intersects the ray a segment leaves behind twice, as the probe of segment f and as the
@@ -1344,9 +1346,7 @@ PT_DEV void lane_closest_done(const DevScene& sc, Lane& L) {
 template <unsigned MATS, bool MEDIUM>
 PT_DEV void lane_back(const DevScene& sc, Lane& L) {
     f3 sh_o = L.h.pos;
-    L.a = splat(0.0f);
     if (L.kind == K_SURFACE_MIS) {
-        L.vis = splat(0.0f);
         const Mat mat = load_mat((L.mesh_id + 1) ? &sc.mats[L.mesh_id + 1] : &sc.mats[sc.n_meshes + 1]);
         if (L.w2_ran && L.h.didHit) {                                    // the probe ray, base.cl:58-75
             const int mid = L.h.mesh_id;
@@ -1405,97 +1405,6 @@ PT_DEV Ray lane_shadow_ray(const Lane& L) {
 template <bool MEDIUM>
 PT_DEV void lane_finish(const DevScene& sc, Lane& L) {
     lane_finish_segment<MEDIUM>(sc, L, splat(0.0f), 1.0f, L.kind == K_SURFACE_MIS, false, L.sh && !L.occluded);
-}
-
-
-// ---- parking a lane's context ---------------------------------------------------------------------------------
-// render_kernel time-multiplexes K pixels per lane: between two passes of a context only what is listed here survives
-// (a lane is parked either idle, waiting for a closest-hit walk, or -- rarely -- on its way to lane_back).  Everything
-// else of Lane is dead at that point: the shadow-ray terms live inside one pass, the hit cache is consumed by the
-// lane_front of the pass that produced it.  tests/emu parks and unparks through these same functions around every
-// pass, into a poisoned Lane, so a field missing here fails on the CPU.
-#define PT_PARK_BASE 34
-#define PT_PARK_MEDIUM 17
-template <bool MEDIUM>
-struct Parked { unsigned w[PT_PARK_BASE + (MEDIUM ? PT_PARK_MEDIUM : 0)]; };
-
-enum {
-    PF_STAGE = 7u, PF_BEGUN = 1u << 3, PF_W2 = 1u << 4, PF_W2_RAN = 1u << 5, PF_TERMINATE = 1u << 6, PF_KIND = 3u << 7, PF_WAS_SPECULAR = 1u << 9,
-    PF_RESET = 1u << 10, PF_WALK_DONE = 1u << 11, PF_WALK_FOUND = 1u << 12, PF_SH = 1u << 13, PF_OFF = 1u << 14, PF_POOLED = 1u << 15
-};
-
-// `off`: the lane has no pixel in this context (ragged frame edge); `pooled`: its walk result arrives in LDS
-template <bool MEDIUM>
-PT_DEV void lane_pack(const Lane& L, const bool off, const bool pooled, Parked<MEDIUM>& P) {
-    unsigned* w = P.w;
-    w[0] = prt_f2u(L.mask.x); w[1] = prt_f2u(L.mask.y); w[2] = prt_f2u(L.mask.z);
-    w[3] = prt_f2u(L.acc[0]); w[4] = prt_f2u(L.acc[1]); w[5] = prt_f2u(L.acc[2]); w[6] = prt_f2u(L.acc[3]);
-    w[7] = L.total; w[8] = L.samples;
-    w[9] = (L.diff & 0xffffu) | (L.spec << 16); w[10] = (L.trans & 0xffffu) | (L.scatters << 16);
-    w[11] = prt_f2u(L.origin.x); w[12] = prt_f2u(L.origin.y); w[13] = prt_f2u(L.origin.z);
-    w[14] = prt_f2u(L.dir.x); w[15] = prt_f2u(L.dir.y); w[16] = prt_f2u(L.dir.z);
-    w[17] = prt_f2u(L.t); w[18] = prt_f2u(L.time);
-    w[19] = prt_f2u(L.h.normal.x); w[20] = prt_f2u(L.h.normal.y); w[21] = prt_f2u(L.h.normal.z);     // = n_shade while a probe is out
-    w[22] = L.rng.s0; w[23] = L.rng.s1;
-    w[24] = prt_f2u(L.wi.x); w[25] = prt_f2u(L.wi.y); w[26] = prt_f2u(L.wi.z);
-    w[27] = prt_f2u(L.weight.x); w[28] = prt_f2u(L.weight.y); w[29] = prt_f2u(L.weight.z);
-    w[30] = prt_f2u(L.pdf);
-    w[31] = (unsigned)L.mesh_id;
-    w[32] = L.f;
-    w[33] = ((unsigned)L.stage & PF_STAGE) | (L.begun ? PF_BEGUN : 0u) | (L.w2 ? PF_W2 : 0u) | (L.w2_ran ? PF_W2_RAN : 0u) |
-            (L.terminate ? PF_TERMINATE : 0u) | (((unsigned)L.kind & 3u) << 7) | (L.wasSpecular ? PF_WAS_SPECULAR : 0u) |
-            (L.reset ? PF_RESET : 0u) | (L.w.done ? PF_WALK_DONE : 0u) | (L.w.found ? PF_WALK_FOUND : 0u) | (L.sh ? PF_SH : 0u) |
-            (off ? PF_OFF : 0u) | (pooled ? PF_POOLED : 0u) | ((L.sampledLobe & 0xffu) << 16);
-    if (MEDIUM) {
-        unsigned* m = P.w + PT_PARK_BASE;
-        m[0] = prt_f2u(L.ms_p.x); m[1] = prt_f2u(L.ms_p.y); m[2] = prt_f2u(L.ms_p.z);
-        m[3] = prt_f2u(L.ps_w.x); m[4] = prt_f2u(L.ps_w.y); m[5] = prt_f2u(L.ps_w.z);
-        m[6] = prt_f2u(L.ps_weight.x); m[7] = prt_f2u(L.ps_weight.y); m[8] = prt_f2u(L.ps_weight.z);
-        m[9] = prt_f2u(L.ps_pdf);
-        m[10] = prt_f2u(L.vis.x); m[11] = prt_f2u(L.vis.y); m[12] = prt_f2u(L.vis.z);
-        m[13] = prt_f2u(L.sh_d.x); m[14] = prt_f2u(L.sh_d.y); m[15] = prt_f2u(L.sh_d.z);
-        m[16] = prt_f2u(L.sh_tmax);
-    }
-}
-
-// the counterpart; a walk that ended at the root without a hit is rebuilt here (t = INF, nothing found), a pooled
-// one is filled in by the caller from LDS
-template <bool MEDIUM>
-PT_DEV void lane_unpack(const Parked<MEDIUM>& P, Lane& L, bool& off, bool& pooled) {
-    const unsigned* w = P.w;
-    lane_init(L);
-    L.mask = F3(prt_u2f(w[0]), prt_u2f(w[1]), prt_u2f(w[2]));
-    L.acc[0] = prt_u2f(w[3]); L.acc[1] = prt_u2f(w[4]); L.acc[2] = prt_u2f(w[5]); L.acc[3] = prt_u2f(w[6]);
-    L.total = w[7]; L.samples = w[8];
-    L.diff = w[9] & 0xffffu; L.spec = w[9] >> 16; L.trans = w[10] & 0xffffu; L.scatters = w[10] >> 16;
-    L.origin = F3(prt_u2f(w[11]), prt_u2f(w[12]), prt_u2f(w[13]));
-    L.dir = F3(prt_u2f(w[14]), prt_u2f(w[15]), prt_u2f(w[16]));
-    L.t = prt_u2f(w[17]); L.time = prt_u2f(w[18]);
-    L.h.normal = F3(prt_u2f(w[19]), prt_u2f(w[20]), prt_u2f(w[21]));
-    L.n_shade = L.h.normal;
-    L.rng.s0 = w[22]; L.rng.s1 = w[23];
-    L.wi = F3(prt_u2f(w[24]), prt_u2f(w[25]), prt_u2f(w[26]));
-    L.weight = F3(prt_u2f(w[27]), prt_u2f(w[28]), prt_u2f(w[29]));
-    L.pdf = prt_u2f(w[30]);
-    L.mesh_id = (int)w[31];
-    L.f = w[32];
-    const unsigned b = w[33];
-    L.stage = (int)(b & PF_STAGE); L.begun = (b & PF_BEGUN) != 0; L.w2 = (b & PF_W2) != 0; L.w2_ran = (b & PF_W2_RAN) != 0;
-    L.terminate = (b & PF_TERMINATE) != 0; L.kind = (int)((b >> 7) & 3u); L.wasSpecular = (b & PF_WAS_SPECULAR) != 0;
-    L.reset = (b & PF_RESET) != 0; L.w.done = (b & PF_WALK_DONE) != 0; L.w.found = (b & PF_WALK_FOUND) != 0; L.sh = (b & PF_SH) != 0;
-    off = (b & PF_OFF) != 0; pooled = (b & PF_POOLED) != 0;
-    L.sampledLobe = (b >> 16) & 0xffu;
-    L.w.t = PT_INF;
-    if (MEDIUM) {
-        const unsigned* m = P.w + PT_PARK_BASE;
-        L.ms_p = F3(prt_u2f(m[0]), prt_u2f(m[1]), prt_u2f(m[2]));
-        L.ps_w = F3(prt_u2f(m[3]), prt_u2f(m[4]), prt_u2f(m[5]));
-        L.ps_weight = F3(prt_u2f(m[6]), prt_u2f(m[7]), prt_u2f(m[8]));
-        L.ps_pdf = prt_u2f(m[9]);
-        L.vis = F3(prt_u2f(m[10]), prt_u2f(m[11]), prt_u2f(m[12]));
-        L.sh_d = F3(prt_u2f(m[13]), prt_u2f(m[14]), prt_u2f(m[15]));
-        L.sh_tmax = prt_u2f(m[16]);
-    }
 }
 
 }  // namespace dev

@@ -4,10 +4,10 @@
 //   state_to_rtd / rtd_to_state   80 B/px SoA planes <-> the reference's 112 B RTD records
 //   count_kernel                  sum of samples / segments / frozen pixels (Msamples/s accounting)
 //
-// Launch geometry: one wave per workgroup, owning K horizontally adjacent 8x8 pixel tiles (K pixels per lane);
-// dynamic LDS holds the traversal stacks, the wave's deep-ray pool and the walk results.  A 1920x1080 frame is
-// 8 100 workgroups of 256 pixels for 256 CUs x 8 resident waves, rendered as two interleaved sets of tile groups on
-// two streams (prt_api.cpp).
+// Launch geometry: one wave per workgroup, owning an 8x8 pixel tile (primary rays of one wave walk the same
+// BVH nodes); dynamic LDS (DevScene::stack_levels x 256 B per workgroup) holds the traversal stacks.  A
+// 1920x1080 frame is 32 400 workgroups >> 256 CUs x 16 resident waves, rendered as two interleaved sets of
+// tiles on two streams (prt_api.cpp).
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -26,203 +26,112 @@ using namespace dev;
 #define PT_BLOCK 64         // threads per workgroup: ONE wave.  A workgroup's slot (LDS, dispatch) frees only when its last wave
                             // ends, and waves over the mesh run ~3x longer than waves over a wall: one-wave groups +4 % over 256
 
-// One wave owns K horizontally adjacent 8x8 tiles and time-multiplexes them: lane l holds pixel l of every tile.  The
-// contexts of the K - 1 pixels a lane is not working on are PARKED IN VECTOR REGISTERS (pt_device.h lane_pack: 34
-// dwords, 51 with a medium): at two waves per SIMD a wave has 256 VGPRs, the live context and the shading code need
-// about 128, and the register file (512 KB per CU) is the only on-chip memory large enough -- 160 KB of LDS would hold
-// one parked context per wave at this occupancy, HBM round trips are what sank the round-1 wavefront pipeline.
-// One ROUND of the wave:
-//   for k in 0..K-1 (a PASS, straight-line code at the lane occupancy of a plain megakernel):
-//       unpark context k; answer its walk (lane_closest_done), lane_back + shadow walk + lane_finish of the segment,
-//       lane_front of the next one, the ROOT step of the walk it asks for (6 rays in 10 end there); park.
-//       A ray that goes deeper is pushed to the wave's ray pool in LDS (ballot-ranked compaction).
-//   the BATCH WALK: the deep rays of all K contexts, one per lane, walk together; results go back through LDS.
-// So the shading passes stay dense while the one expensive loop of the kernel -- a wave waiting for its deepest
-// BVH walk -- is paid once per K tiles and runs with K times the lanes (the regrouping the per-tile megakernel lacked:
-// 11 % of its walk-step lanes were active).  Shadow rays (99 % end at the root) walk inside the pass.
-// A lane whose segment needs W1 and W2 (path restart) takes two rounds for it and falls a frame behind its
-// neighbours; that is legal because pixels are independent (seeds are a function of the lane's own frame number).
-#define PT_POOL_CAP 128
-struct PoolEntry { float4 o_tmax; float4 d_id; uint4 node_far; };
-
-// The parked contexts are K separate objects that are only ever touched with compile-time slot numbers, so every parked
-// word is an SSA value in a VGPR (an array indexed by the pass counter -- or stores selected by it -- would live in
-// scratch memory).  The passes therefore ROTATE the slots: a pass takes its context from slot 0 and leaves it in slot
-// K - 1, the others move down one slot; after K passes every context is back where it started.
-template <bool MEDIUM, int K>
-__device__ __forceinline__ void rotate_in(Parked<MEDIUM>& p0, Parked<MEDIUM>& p1, Parked<MEDIUM>& p2, Parked<MEDIUM>& p3, Parked<MEDIUM>& p4,
-                                          Parked<MEDIUM>& p5, const Parked<MEDIUM>& last) {
-    if (K > 1) p0 = p1;
-    if (K > 2) p1 = p2;
-    if (K > 3) p2 = p3;
-    if (K > 4) p3 = p4;
-    if (K > 5) p4 = p5;
-    (K == 1 ? p0 : K == 2 ? p1 : K == 3 ? p2 : K == 4 ? p3 : K == 5 ? p4 : p5) = last;
-}
-#define PT_PARKED_ARGS(P) P##0, P##1, P##2, P##3, P##4, P##5
-
-template <unsigned MATS, bool MEDIUM, int WAVES, int K>
+// One wave = one 8x8 tile; every lane runs the lane machine of pt_device.h on its pixel until it has done its n_frames
+// segments (or froze).  What is wave-level here is only the SCHEDULE: when the two walk phases of an iteration end.
+//   walk phase rule: go on while at least fa.walk_min_lanes lanes are still walking; below that, stop as soon as the
+//   iteration has something else to do (a lane finished its walk in this phase, or lanes are waiting in a later stage).
+//   A lane cut off keeps its WalkState and LDS stack and resumes in the same phase of the next iteration.
+// WAVES = waves per SIMD the register allocator leaves room for.
+template <unsigned MATS, bool MEDIUM, int WAVES>
 __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene sc, const DevCamera cam, const DevState S,
                                                                  const FrameArgs fa, float4* __restrict__ fb) {
-    static_assert(K >= 1 && K <= 6, "contexts per lane");
-    const int tiles_x = (fa.width + 7) / 8, groups_x = (tiles_x + K - 1) / K;
-    const unsigned group = blockIdx.x * fa.tile_stride + fa.tile_first;
-    const int group_x = (int)(group % (unsigned)groups_x), tile_y = (int)(group / (unsigned)groups_x);
+    const int tiles_x = (fa.width + 7) / 8;
+    const unsigned tile = blockIdx.x * fa.tile_stride + fa.tile_first;
+    const int tile_x = (int)(tile % (unsigned)tiles_x), tile_y = (int)(tile / (unsigned)tiles_x);
     const int lane = threadIdx.x & 63;
+    const int lx = tile_x * 8 + (lane & 7);
     const int ly = tile_y * 8 + (lane >> 3);
+    if (lx >= fa.width || ly >= fa.rows) return;                // no barriers in this kernel
+    const size_t id = (size_t)ly * (size_t)fa.width + (size_t)lx;
+    const int gx = lx;
     const int gy = fa.row0 + (ly / fa.block_rows * fa.n_parts + fa.part) * fa.block_rows + ly % fa.block_rows;
-    const int lx0 = group_x * K * 8 + (lane & 7);               // pixel column of context k: lx0 + 8 k
 
-    extern __shared__ unsigned lds_words[];                     // [stack: levels x 64][pool: PT_POOL_CAP x 12][results: K x 64 x 4]
+    Lane L;
+    lane_init(L);
+    {
+        const float4 a = S.q0[id], b = S.q1[id], c = S.q2[id], d = S.q3[id];
+        const uint4 e = S.q4[id];
+        L.origin = F3(a.x, a.y, a.z); L.t = a.w;                // TempRay.time = ray.t of the last segment (main.cl:28)
+        L.dir = F3(b.x, b.y, b.z); L.time = b.w;                // TempRay.dist = ray.time
+        L.mask = F3(c.x, c.y, c.z); L.total = prt_f2u(c.w);
+        L.acc[0] = d.x; L.acc[1] = d.y; L.acc[2] = d.z; L.acc[3] = d.w;
+        L.samples = e.x;
+        L.diff = e.y & 0xffffu; L.spec = e.y >> 16;
+        L.trans = e.z & 0xffffu; L.scatters = e.z >> 16;
+        L.wasSpecular = (e.w & 1u) != 0; L.reset = (e.w & 2u) != 0;
+    }
+    extern __shared__ unsigned lds_stack[];                     // sc.stack_levels x PT_BLOCK, sized by the launch
     TravStack stk;
-    stk.lds = lds_words + threadIdx.x; stk.stride = PT_BLOCK;
-    PoolEntry* const pool = reinterpret_cast<PoolEntry*>(lds_words + sc.stack_levels * PT_BLOCK);
-    uint4* const results = reinterpret_cast<uint4*>(pool + PT_POOL_CAP);
-
-    Parked<MEDIUM> P0, P1, P2, P3, P4, P5;                     // slots K.. stay unused (and cost nothing)
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        Lane L;
-        lane_init(L);
-        const int lx = lx0 + 8 * k;
-        const bool off = lx >= fa.width || ly >= fa.rows;
-        if (!off) {
-            const size_t id = (size_t)ly * (size_t)fa.width + (size_t)lx;
-            const float4 a = S.q0[id], b = S.q1[id], c = S.q2[id], d = S.q3[id];
-            const uint4 e = S.q4[id];
-            L.origin = F3(a.x, a.y, a.z); L.t = a.w;            // TempRay.time = ray.t of the last segment (main.cl:28)
-            L.dir = F3(b.x, b.y, b.z); L.time = b.w;            // TempRay.dist = ray.time
-            L.mask = F3(c.x, c.y, c.z); L.total = prt_f2u(c.w);
-            L.acc[0] = d.x; L.acc[1] = d.y; L.acc[2] = d.z; L.acc[3] = d.w;
-            L.samples = e.x;
-            L.diff = e.y & 0xffffu; L.spec = e.y >> 16;
-            L.trans = e.z & 0xffffu; L.scatters = e.z >> 16;
-            L.wasSpecular = (e.w & 1u) != 0; L.reset = (e.w & 2u) != 0;
-        }
-        Parked<MEDIUM> pk;
-        lane_pack<MEDIUM>(L, off, false, pk);
-        rotate_in<MEDIUM, K>(PT_PARKED_ARGS(P), pk);
-    }
-    unsigned pool_n = 0;                                        // wave-uniform
-    // the deep rays collected so far, one per lane, walked to their end; results to LDS by (context, lane)
-    auto batch_walk = [&]() {
-        __syncthreads();                                        // one wave per workgroup: orders the pool writes before the reads
-        while (pool_n) {
-            const unsigned n = pool_n < 64u ? pool_n : 64u;
-            const unsigned base = pool_n - n;
-            if ((unsigned)lane < n) {
-                const PoolEntry e = pool[base + (unsigned)lane];
-                Ray wr;
-                wr.origin = F3(e.o_tmax.x, e.o_tmax.y, e.o_tmax.z); wr.dir = F3(e.d_id.x, e.d_id.y, e.d_id.z);
-                wr.normal = splat(0.0f); wr.pos = splat(0.0f); wr.t = e.o_tmax.w; wr.backside = false; wr.time = 0.0f;
-                const RayPre p = ray_pre(wr);
-                WalkState w;
-                w.found = false; w.done = false; w.t = e.o_tmax.w;
-                w.th.u = w.th.v = w.th.w = 0.0f; w.th.slot = 0;
-                w.node = e.node_far.x; w.sp = 0;
-                if (e.node_far.y != 0xFFFFFFFFu) { stk.lds[0] = e.node_far.y; w.sp = 1; }
-                for (;;) {
-                    walk_step(sc, false, wr, p, w, stk);
-                    if (w.done) break;
-                }
-                results[prt_f2u(e.d_id.w)] = make_uint4(prt_f2u(w.t), prt_f2u(w.th.u), prt_f2u(w.th.v), w.th.slot | (w.found ? 0x80000000u : 0u));
-            }
-            pool_n = base;
-        }
-        __syncthreads();
-    };
+    stk.lds = lds_stack + threadIdx.x; stk.stride = PT_BLOCK;
+    const unsigned T = fa.walk_min_lanes;
     for (;;) {
-        bool any_live = false;                                  // wave-uniform: some lane of some context still has work
-#pragma nounroll
-        for (int k = 0; k < K; ++k) {
-            if (pool_n > (unsigned)(PT_POOL_CAP - 64)) batch_walk();           // room for this context's deep rays
-            Lane L;
-            bool off, pooled;
-            lane_unpack<MEDIUM>(P0, L, off, pooled);               // pass k of a round finds context k in slot 0
-            const int gx = lx0 + 8 * k;
-            if (pooled) {                                       // the batch walk's answer
-                const uint4 r = results[k * 64 + lane];
-                L.w.t = prt_u2f(r.x); L.w.th.u = prt_u2f(r.y); L.w.th.v = prt_u2f(r.z); L.w.th.w = 1.0f - L.w.th.u - L.w.th.v;   // triangle.cl:24
-                L.w.th.slot = r.w & 0x7fffffffu; L.w.found = (r.w >> 31) != 0; L.w.done = true;
-                pooled = false;
-            }
-            if (L.stage == ST_WALKC && L.w.done) lane_closest_done<MATS, MEDIUM>(sc, L);
-            for (;;) {
-                if (L.stage == ST_BACK) lane_back<MATS, MEDIUM>(sc, L);
-                {                                               // the shadow ray's any-hit walk, to its end
-                    const bool walking = L.stage == ST_WALKS;
-                    const Ray wr = lane_shadow_ray<MEDIUM>(L);
-                    const RayPre p = ray_pre(wr);
-                    if (walking) {
-                        walk_begin(sc, true, wr, wr.t, p, L.w, stk);
-                        while (!L.w.done) walk_step(sc, true, wr, p, L.w, stk);
-                        L.occluded = L.w.found; L.stage = ST_FINISH;
-                    }
+        const bool runnable = lane_runnable(fa, L);
+        if (!__any(runnable || L.stage != ST_READY)) break;     // every lane has done its frames (or is frozen)
+        if (runnable) lane_front<MATS, MEDIUM>(sc, cam, fa, L, gx, gy);                                  // A
+        {                                                                                                 // B
+            const bool walking = L.stage == ST_WALKC;
+            const Ray wr = lane_closest_ray<MEDIUM>(L);
+            const RayPre p = ray_pre(wr);
+            if (walking && L.fresh) { walk_begin(sc, false, wr, PT_INF, p, L.w, stk); L.fresh = false; }
+            const bool go = walking && !L.w.done;
+            const unsigned n_start = (unsigned)__popcll(__ballot(go));
+            const bool other_work = __any((walking && L.w.done) || L.stage == ST_BACK);
+            if (go) {
+                for (;;) {
+                    walk_step(sc, false, wr, p, L.w, stk);
+                    if (L.w.done) break;
+                    const unsigned n_act = (unsigned)__popcll(__ballot(1));
+                    if (n_act < T && (n_act < n_start || other_work)) break;
                 }
-                if (L.stage == ST_FINISH) lane_finish<MEDIUM>(sc, L);
-                if (!off && lane_runnable(fa, L)) lane_front<MATS, MEDIUM>(sc, cam, fa, L, gx, gy);
-                if (!__any(L.stage == ST_BACK)) break;          // BSDF sampling failed under MIS (no probe, base.cl:168-172): rare
             }
-            {                                                   // the step at the root, dense; deeper rays go to the pool
-                const bool fresh = L.stage == ST_WALKC && L.fresh;
-                const Ray wr = lane_closest_ray<MEDIUM>(L);
-                bool deep = false;
-                if (fresh) {
-                    const RayPre p = ray_pre(wr);
-                    walk_begin(sc, false, wr, PT_INF, p, L.w, stk);
-                    L.fresh = false;
-                    deep = !L.w.done;
-                }
-                const unsigned long long m = __ballot(deep);   // every lane of the wave is here: pool_n stays wave-uniform
-                if (deep) {
-                    const unsigned idx = pool_n + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-                    PoolEntry e;
-                    e.o_tmax = make_float4(wr.origin.x, wr.origin.y, wr.origin.z, PT_INF);
-                    e.d_id = make_float4(wr.dir.x, wr.dir.y, wr.dir.z, prt_u2f((unsigned)(k * 64 + lane)));
-                    e.node_far = make_uint4(L.w.node, L.w.sp ? stk.lds[0] : 0xFFFFFFFFu, 0u, 0u);
-                    pool[idx] = e;
-                    pooled = true;
-                }
-                pool_n += (unsigned)__popcll(m);
-            }
-            any_live = any_live || __any(!off && (L.stage != ST_READY || lane_runnable(fa, L)));
-            Parked<MEDIUM> pk;
-            lane_pack<MEDIUM>(L, off, pooled, pk);
-            rotate_in<MEDIUM, K>(PT_PARKED_ARGS(P), pk);
+            if (walking && L.w.done) lane_closest_done<MATS, MEDIUM>(sc, L);
         }
-        if (pool_n) batch_walk();
-        if (!any_live) break;
-    }
-    unsigned long long unfinished_px = 0;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        Lane L;
-        bool off, pooled;
-        lane_unpack<MEDIUM>(P0, L, off, pooled);
-        rotate_in<MEDIUM, K>(PT_PARKED_ARGS(P), P0);
-        if (!off && L.f) {
-            const size_t id = (size_t)ly * (size_t)fa.width + (size_t)(lx0 + 8 * k);
-            S.q0[id] = make_float4(L.origin.x, L.origin.y, L.origin.z, L.t);
-            S.q1[id] = make_float4(L.dir.x, L.dir.y, L.dir.z, L.time);
-            S.q2[id] = make_float4(L.mask.x, L.mask.y, L.mask.z, prt_u2f(L.total));
-            S.q3[id] = make_float4(L.acc[0], L.acc[1], L.acc[2], L.acc[3]);
-            S.q4[id] = make_uint4(L.samples, (L.diff & 0xffffu) | (L.spec << 16), (L.trans & 0xffffu) | (L.scatters << 16),
-                                  (L.wasSpecular ? 1u : 0u) | (L.reset ? 2u : 0u));
-            const float ns = (float)L.samples;                                     // write_imagef, main.cl:159
-            fb[id] = make_float4(L.acc[0] / ns, L.acc[1] / ns, L.acc[2] / ns, L.acc[3] / ns);
+        if (L.stage == ST_BACK) lane_back<MATS, MEDIUM>(sc, L);                                          // C
+        {                                                                                                 // D
+            const bool walking = L.stage == ST_WALKS;
+            const Ray wr = lane_shadow_ray<MEDIUM>(L);
+            const RayPre p = ray_pre(wr);
+            if (walking && L.fresh) { walk_begin(sc, true, wr, wr.t, p, L.w, stk); L.fresh = false; }
+            const bool go = walking && !L.w.done;
+            const unsigned n_start = (unsigned)__popcll(__ballot(go));
+            const bool other_work = __any((walking && L.w.done) || L.stage == ST_FINISH);
+            if (go) {
+                for (;;) {
+                    walk_step(sc, true, wr, p, L.w, stk);
+                    if (L.w.done) break;
+                    const unsigned n_act = (unsigned)__popcll(__ballot(1));
+                    if (n_act < T && (n_act < n_start || other_work)) break;
+                }
+            }
+            if (walking && L.w.done) { L.occluded = L.w.found; L.stage = ST_FINISH; }
         }
-        unfinished_px += (unsigned long long)__popcll(__ballot(!off && !(fa.spp_limit && L.reset && L.samples >= fa.spp_limit)));
+        if (L.stage == ST_FINISH) lane_finish<MEDIUM>(sc, L);                                            // E
     }
-    if (fa.unfinished && lane == 0) {
-        // returning atomic: its value is back only once the add has been performed at the device's coherence point
-        const unsigned long long before = unfinished_px ? atomicAdd(fa.unfinished, unfinished_px) : 0ull;
-        if (fa.unfinished_host && before != ~0ull) {           // (never equal: the test orders the ticket behind the add without a
-            // fence -- a device-scope fence writes back and invalidates this XCD's L2, 2.5 % when every wave does it)
-            // The last wave of the launch hands the total to the host and leaves the counters clean for the next launch.
-            if (atomicAdd(fa.unfinished + 1, 1ull) == (unsigned long long)gridDim.x - 1ull) {
-                const unsigned long long total = atomicExch(fa.unfinished, 0ull);
-                atomicExch(fa.unfinished + 1, 0ull);
-                *reinterpret_cast<volatile unsigned long long*>(fa.unfinished_host) = total;   // visible to the host at kernel end
+    if (L.f) {
+        S.q0[id] = make_float4(L.origin.x, L.origin.y, L.origin.z, L.t);
+        S.q1[id] = make_float4(L.dir.x, L.dir.y, L.dir.z, L.time);
+        S.q2[id] = make_float4(L.mask.x, L.mask.y, L.mask.z, prt_u2f(L.total));
+        S.q3[id] = make_float4(L.acc[0], L.acc[1], L.acc[2], L.acc[3]);
+        S.q4[id] = make_uint4(L.samples, (L.diff & 0xffffu) | (L.spec << 16), (L.trans & 0xffffu) | (L.scatters << 16),
+                              (L.wasSpecular ? 1u : 0u) | (L.reset ? 2u : 0u));
+        const float ns = (float)L.samples;                                     // write_imagef, main.cl:159
+        fb[id] = make_float4(L.acc[0] / ns, L.acc[1] / ns, L.acc[2] / ns, L.acc[3] / ns);
+    }
+    if (fa.unfinished) {
+        const bool unfinished = !(fa.spp_limit && L.reset && L.samples >= fa.spp_limit);
+        const unsigned long long m = __ballot(unfinished);
+        if (lane == (int)__builtin_ctzll(__ballot(1))) {
+            // returning atomic: its value is back only once the add has been performed at the device's coherence point
+            const unsigned long long before = m ? atomicAdd(fa.unfinished, (unsigned long long)__popcll(m)) : 0ull;
+            if (fa.unfinished_host && before != ~0ull) {       // (never equal: the test orders the ticket behind the add without a
+                // fence -- a device-scope fence writes back and invalidates this XCD's L2, 2.5 % when every wave does it)
+                // The last wave of the launch hands the total to the host and leaves the counters clean for the next launch
+                // (every 8x8 tile holds at least one pixel of the frame, so every wave of the grid gets here).
+                if (atomicAdd(fa.unfinished + 1, 1ull) == (unsigned long long)gridDim.x - 1ull) {
+                    const unsigned long long total = atomicExch(fa.unfinished, 0ull);
+                    atomicExch(fa.unfinished + 1, 0ull);
+                    *reinterpret_cast<volatile unsigned long long*>(fa.unfinished_host) = total;   // visible to the host at kernel end
+                }
             }
         }
     }
@@ -368,36 +277,32 @@ __global__ void selftest_math_kernel(int fn, const float* __restrict__ a, const 
 }
 
 // ---- host-side launchers -------------------------------------------------------------------------------
-#ifndef PT_CONTEXTS
-#define PT_CONTEXTS 4       // pixels per lane (K): 3 x 34 parked dwords + the live context fit 256 VGPRs
-#endif
-#ifndef PT_CONTEXTS_MEDIUM
-#define PT_CONTEXTS_MEDIUM 3   // 51 parked dwords per context with a medium
-#endif
-#ifndef PT_WAVES
-#define PT_WAVES 2          // waves per SIMD = 512 / VGPR budget
-#endif
-static unsigned render_contexts(const DevScene& sc) { return sc.has_medium ? PT_CONTEXTS_MEDIUM : PT_CONTEXTS; }
-unsigned render_group_count(const DevScene& sc, int width, int rows) {
-    const unsigned K = render_contexts(sc);
-    const unsigned tiles_x = ((unsigned)width + 7u) / 8u, tiles_y = ((unsigned)rows + 7u) / 8u;
-    return ((tiles_x + K - 1u) / K) * tiles_y;
+template <unsigned MATS, bool MEDIUM, int WAVES>
+static void launch_variant_w(const DevScene& sc, const DevCamera& cam, const DevState& S, const FrameArgs& fa, float4* fb,
+                             hipStream_t stream) {
+    const unsigned tiles_x = ((unsigned)fa.width + 7u) / 8u, tiles_y = ((unsigned)fa.rows + 7u) / 8u;
+    const size_t lds = (size_t)sc.stack_levels * PT_BLOCK * sizeof(unsigned);
+    static size_t lds_attr = 0;                                  // per template instance
+    if (lds > 65536u && lds > lds_attr) {   // only a 4-wave build with a tree that fills the reference's 64-entry stack to the brim
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<MATS, MEDIUM, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        lds_attr = lds;
+    }
+    const unsigned n_tiles = tiles_x * tiles_y;
+    if (fa.tile_first >= n_tiles) return;
+    const unsigned grid = (n_tiles - fa.tile_first + fa.tile_stride - 1) / fa.tile_stride;      // tiles of this sub-part
+    hipLaunchKernelGGL((render_kernel<MATS, MEDIUM, WAVES>), dim3(grid), dim3(PT_BLOCK), lds, stream, sc, cam, S, fa, fb);
 }
-
 template <unsigned MATS, bool MEDIUM>
 static void launch_variant(const DevScene& sc, const DevCamera& cam, const DevState& S, const FrameArgs& fa, float4* fb,
                            hipStream_t stream) {
-    constexpr int K = MEDIUM ? PT_CONTEXTS_MEDIUM : PT_CONTEXTS;
-    const size_t lds = ((size_t)sc.stack_levels * PT_BLOCK + (size_t)PT_POOL_CAP * 12u + (size_t)K * 64u * 4u) * sizeof(unsigned);
-    static size_t lds_attr = 0;                                  // per template instance
-    if (lds > 65536u && lds > lds_attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<MATS, MEDIUM, PT_WAVES, K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        lds_attr = lds;
-    }
-    const unsigned n_groups = render_group_count(sc, fa.width, fa.rows);
-    if (fa.tile_first >= n_groups) return;
-    const unsigned grid = (n_groups - fa.tile_first + fa.tile_stride - 1) / fa.tile_stride;     // groups of this sub-part
-    hipLaunchKernelGGL((render_kernel<MATS, MEDIUM, PT_WAVES, K>), dim3(grid), dim3(PT_BLOCK), lds, stream, sc, cam, S, fa, fb);
+    static const int forced = [] { const char* e = std::getenv("PRT_WAVES"); return e ? std::atoi(e) : 0; }();   // 4 / 5: override (tests, experiments)
+    // 5 waves where latency rules: the node records alone exceed one XCD's L2, or the scene raymarches SDFs (+11 %)
+    const bool big = forced ? forced >= 5 : (sc.n_pairs > 65536u || sc.n_sdfs != 0u);
+#ifndef PT_DEV_ONE_VARIANT
+    if (big) launch_variant_w<MATS, MEDIUM, 5>(sc, cam, S, fa, fb, stream);
+    else
+#endif
+    launch_variant_w<MATS, MEDIUM, PT_MIN_WAVES>(sc, cam, S, fa, fb, stream);
 }
 
 // Variant choice = the AOT analogue of the reference's per-scene program build (include/CL/cl_kernel.h):
@@ -425,6 +330,10 @@ const char* launch_render(const DevScene& sc, const DevCamera& cam, const DevSta
     launch_variant<0u, true>(sc, cam, S, fa, fb, stream);
     return "render_kernel<generic,medium>";
 #endif
+}
+
+unsigned render_tile_count(int width, int rows) {
+    return (((unsigned)width + 7u) / 8u) * (((unsigned)rows + 7u) / 8u);
 }
 
 void make_dev_camera(const prt_camera& in, DevCamera& out) {

@@ -11,8 +11,8 @@ namespace prt {
 // build, include/CL/cl_kernel.h); returns the variant's name for profiles/stats
 const char* launch_render(const DevScene& sc, const DevCamera& cam, const DevState& S, const FrameArgs& fa, float4* fb,
                           hipStream_t stream);
-// workgroups launch_render uses for a width x rows frame part: one wave per group of K horizontally adjacent 8x8 tiles
-unsigned render_group_count(const DevScene& sc, int width, int rows);
+// workgroups (tiles) launch_render uses for a width x rows frame part
+unsigned render_tile_count(int width, int rows);
 // per-camera part of createCamRay (camera.cl:19-28), on the host with the arithmetic of pt_device.h
 void make_dev_camera(const prt_camera& in, DevCamera& out);
 void launch_state_to_rtd(const DevState& S, prt_path_state* out, size_t n, hipStream_t stream);

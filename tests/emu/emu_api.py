@@ -1,5 +1,5 @@
 """tests/emu/emu_api.py -- TEST INFRASTRUCTURE: builds and binds tests/emu/libpt_emu.so, the product's device header
-(csrc/hip/pt_device.h) compiled for the host and driven through the passes of render_kernel (pt_emu.cpp)."""
+(csrc/hip/pt_device.h) compiled for the host and driven by a wave emulator (pt_emu.cpp)."""
 import ctypes as C
 import os
 import subprocess
@@ -37,12 +37,12 @@ def lib():
         _lib.emu_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
-                                    C.c_uint32, C.c_char_p, C.c_int]
+                                    C.c_uint32, C.c_uint32, C.c_uint32, C.c_char_p, C.c_int]
     return _lib
 
 
 def render(state_dtype, cfg, desc, camera, W, H, seed_pairs, first_frame=1, state=None, env=None, spp_limit=0,
-           row0=0, rows=None, blocks=None, img=None):
+           walk_min_lanes=8, sched_seed=0, row0=0, rows=None, blocks=None, img=None):
     """same call shape as oracle_api.Restatement.render"""
     if blocks is not None:
         rows = sum(1 for r in range(H) if (r // blocks[0]) % blocks[1] == blocks[2])
@@ -62,7 +62,7 @@ def render(state_dtype, cfg, desc, camera, W, H, seed_pairs, first_frame=1, stat
     rc = lib().emu_render(C.cast(C.pointer(cfg), C.c_void_p), C.cast(C.pointer(desc), C.c_void_p), C.cast(C.pointer(camera), C.c_void_p),
                           envp, ew, eh, W, H, row0, rows, b[0], b[1], b[2], first_frame, n_frames,
                           seeds.ctypes.data_as(C.c_void_p), state.ctypes.data_as(C.c_void_p), img.ctypes.data_as(C.c_void_p),
-                          spp_limit, err, 256)
+                          spp_limit, walk_min_lanes, sched_seed, err, 256)
     if rc:
         raise RuntimeError("emu_render failed (%d): %s" % (rc, err.value.decode()))
     return state, img

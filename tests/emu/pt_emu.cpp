@@ -1,10 +1,11 @@
 // tests/emu/pt_emu.cpp -- TEST INFRASTRUCTURE, never part of libprt.
 //
 // The device functions of the product (csrc/hip/pt_device.h: the lane machine, BVH steps, BSDFs, ...) compiled for the
-// HOST (-DPT_EMU turns __device__ into __host__ __device__; hipcc --cuda-host-only) and driven pixel by pixel through
-// the passes of render_kernel (pt_kernels.hip), on the CPU (-m "not gpu"): the lane machine, the parking of a pixel's
-// context between passes and the hand-over of deep rays to the batch walk == the reference goldens and
-// oracle/pt_oracle.c, bit for bit, without a GPU.
+// HOST (-DPT_EMU turns __device__ into __host__ __device__; hipcc --cuda-host-only) and driven by a wave emulator that
+// mirrors render_kernel's schedule (pt_kernels.hip) over 64 Lane records.  Two uses, both on the CPU (-m "not gpu"):
+//   * the refactored per-lane phases == oracle/pt_oracle.c, bit for bit, without a GPU;
+//   * schedule independence: with `sched_seed` != 0 the length of every walk phase is drawn at random, which must not
+//     change a bit of any pixel (lanes drift in frame number; pixels are independent).
 // What this does NOT check is the GPU code generation: that is what the -m gpu parity tests are for.  On the host,
 // hw_recip is the IEEE divide it is exhaustively equal to on the device (prt_selftest_math fn 17).
 #include <hip/hip_runtime.h>
@@ -22,24 +23,28 @@ using namespace prt::dev;
 
 namespace {
 
-// one pixel through render_kernel's passes (pt_kernels.hip), exactly in the kernel's order: unpark into a POISONED Lane
-// (so a field lane_pack forgets shows), answer the walk, lane_back + shadow walk + lane_finish, lane_front, the step at
-// the root, park; a ray that goes deeper is walked the way the kernel's batch walk does it (from {node, far child},
-// result squeezed through {t, u, v, slot | found}).
+struct XorShift {
+    uint32_t s;
+    uint32_t next() { s ^= s << 13; s ^= s >> 17; s ^= s << 5; return s; }
+};
+
 template <unsigned MATS, bool MEDIUM>
-void run_pixel(const DevScene& sc, const DevCamera& cam, const FrameArgs& fa, int lx, int ly, prt_path_state* state, float* out_rgba,
-               std::vector<unsigned>& stack_mem) {
-    const size_t id = (size_t)ly * (size_t)fa.width + (size_t)lx;
-    const int gx = lx;
-    const int gy = fa.row0 + (ly / fa.block_rows * fa.n_parts + fa.part) * fa.block_rows + ly % fa.block_rows;
-    stack_mem.assign((size_t)sc.stack_levels, 0u);
-    TravStack stk;
-    stk.lds = stack_mem.data(); stk.stride = 1;
-    Parked<MEDIUM> P;
-    {
-        Lane l;
+void run_tile(const DevScene& sc, const DevCamera& cam, const FrameArgs& fa, int tile_x, int tile_y, prt_path_state* state, float* out_rgba,
+              uint32_t sched_seed, std::vector<unsigned>& stack_mem) {
+    Lane L[64];
+    bool in_frame[64];
+    int gxs[64], gys[64];
+    size_t ids[64];
+    for (int lane = 0; lane < 64; ++lane) {
+        const int lx = tile_x * 8 + (lane & 7), ly = tile_y * 8 + (lane >> 3);
+        in_frame[lane] = lx < fa.width && ly < fa.rows;
+        if (!in_frame[lane]) continue;
+        ids[lane] = (size_t)ly * (size_t)fa.width + (size_t)lx;
+        gxs[lane] = lx;
+        gys[lane] = fa.row0 + (ly / fa.block_rows * fa.n_parts + fa.part) * fa.block_rows + ly % fa.block_rows;
+        Lane& l = L[lane];
         lane_init(l);
-        const prt_path_state& r = state[id];
+        const prt_path_state& r = state[ids[lane]];
         l.origin = F3(r.origin[0], r.origin[1], r.origin[2]); l.t = r.time;
         l.dir = F3(r.dir[0], r.dir[1], r.dir[2]); l.time = r.dist;
         l.mask = F3(r.mask[0], r.mask[1], r.mask[2]); l.total = r.total;
@@ -47,80 +52,95 @@ void run_pixel(const DevScene& sc, const DevCamera& cam, const FrameArgs& fa, in
         l.samples = r.samples;
         l.diff = r.diff; l.spec = r.spec; l.trans = r.trans; l.scatters = r.scatters;
         l.wasSpecular = r.was_specular != 0; l.reset = r.reset != 0;
-        lane_pack<MEDIUM>(l, false, false, P);
     }
-    uint32_t result[4] = {0, 0, 0, 0};
-    unsigned frames_done = 0;
-    for (;;) {
-        Lane L;
-        std::memset(&L, 0xA5, sizeof(L));                          // poison: everything a pass needs must come out of P
-        bool off, pooled;
-        lane_unpack<MEDIUM>(P, L, off, pooled);
-        if (pooled) {
-            L.w.t = prt_u2f(result[0]); L.w.th.u = prt_u2f(result[1]); L.w.th.v = prt_u2f(result[2]); L.w.th.w = 1.0f - L.w.th.u - L.w.th.v;
-            L.w.th.slot = result[3] & 0x7fffffffu; L.w.found = (result[3] >> 31) != 0; L.w.done = true;
-            pooled = false;
+    stack_mem.assign((size_t)sc.stack_levels * 64, 0u);
+    XorShift xs{sched_seed ? sched_seed * 2654435761u + (uint32_t)(tile_x * 7919 + tile_y) : 0u};
+    if (sched_seed && xs.s == 0) xs.s = 1;
+    auto phase_T = [&]() -> unsigned { return sched_seed ? 1u + xs.next() % 64u : fa.walk_min_lanes; };
+    TravStack stk[64];
+    for (int lane = 0; lane < 64; ++lane) { stk[lane].lds = stack_mem.data() + lane; stk[lane].stride = 64; }
+
+    // one walk phase of the wave (render_kernel B / D)
+    auto walk_phase = [&](const bool any_hit, const int walk_stage, const int waiting_stage) {
+        Ray wr[64];
+        RayPre p[64];
+        bool go[64];
+        unsigned n_start = 0;
+        bool other_work = false;
+        for (int lane = 0; lane < 64; ++lane) {
+            go[lane] = false;
+            if (!in_frame[lane]) continue;
+            Lane& l = L[lane];
+            const bool walking = l.stage == walk_stage;
+            if (walking) {
+                wr[lane] = any_hit ? lane_shadow_ray<MEDIUM>(l) : lane_closest_ray<MEDIUM>(l);
+                p[lane] = ray_pre(wr[lane]);
+                if (l.fresh) { walk_begin(sc, any_hit, wr[lane], any_hit ? wr[lane].t : PT_INF, p[lane], l.w, stk[lane]); l.fresh = false; }
+            }
+            go[lane] = walking && !l.w.done;
+            n_start += go[lane] ? 1u : 0u;
+            other_work |= (walking && l.w.done) || l.stage == waiting_stage;
         }
-        if (L.stage == ST_WALKC && L.w.done) lane_closest_done<MATS, MEDIUM>(sc, L);
+        const unsigned T = phase_T();
         for (;;) {
-            if (L.stage == ST_BACK) lane_back<MATS, MEDIUM>(sc, L);
-            if (L.stage == ST_WALKS) {
-                const Ray wr = lane_shadow_ray<MEDIUM>(L);
-                const RayPre p = ray_pre(wr);
-                walk_begin(sc, true, wr, wr.t, p, L.w, stk);
-                while (!L.w.done) walk_step(sc, true, wr, p, L.w, stk);
-                L.occluded = L.w.found; L.stage = ST_FINISH;
+            unsigned n_act = 0;
+            bool stepped = false;
+            for (int lane = 0; lane < 64; ++lane) {
+                if (!go[lane]) continue;
+                walk_step(sc, any_hit, wr[lane], p[lane], L[lane].w, stk[lane]);
+                stepped = true;
+                if (L[lane].w.done) go[lane] = false; else ++n_act;
             }
-            if (L.stage == ST_FINISH) lane_finish<MEDIUM>(sc, L);
-            if (lane_runnable(fa, L)) lane_front<MATS, MEDIUM>(sc, cam, fa, L, gx, gy);
-            if (L.stage != ST_BACK) break;
+            if (!stepped || n_act == 0) break;
+            if (n_act < T && (n_act < n_start || other_work)) break;
         }
-        if (L.stage == ST_WALKC && L.fresh) {
-            const Ray wr = lane_closest_ray<MEDIUM>(L);
-            const RayPre p = ray_pre(wr);
-            walk_begin(sc, false, wr, PT_INF, p, L.w, stk);
-            L.fresh = false;
-            if (!L.w.done) {                                       // the batch walk of the kernel
-                const unsigned node = L.w.node, far = L.w.sp ? stk.lds[0] : 0xFFFFFFFFu;
-                WalkState w;
-                w.found = false; w.done = false; w.t = PT_INF;
-                w.th.u = w.th.v = w.th.w = 0.0f; w.th.slot = 0;
-                w.node = node; w.sp = 0;
-                if (far != 0xFFFFFFFFu) { stk.lds[0] = far; w.sp = 1; }
-                while (!w.done) walk_step(sc, false, wr, p, w, stk);
-                result[0] = prt_f2u(w.t); result[1] = prt_f2u(w.th.u); result[2] = prt_f2u(w.th.v); result[3] = w.th.slot | (w.found ? 0x80000000u : 0u);
-                pooled = true;
-            }
+    };
+
+    for (;;) {
+        bool any = false;
+        bool runnable[64];
+        for (int lane = 0; lane < 64; ++lane) {
+            runnable[lane] = in_frame[lane] && lane_runnable(fa, L[lane]);
+            any |= in_frame[lane] && (runnable[lane] || L[lane].stage != ST_READY);
         }
-        frames_done = L.f;
-        const bool live = L.stage != ST_READY || lane_runnable(fa, L);
-        lane_pack<MEDIUM>(L, false, pooled, P);
-        if (!live) break;
+        if (!any) break;
+        for (int lane = 0; lane < 64; ++lane)
+            if (runnable[lane]) lane_front<MATS, MEDIUM>(sc, cam, fa, L[lane], gxs[lane], gys[lane]);
+        walk_phase(false, ST_WALKC, ST_BACK);
+        for (int lane = 0; lane < 64; ++lane)
+            if (in_frame[lane] && L[lane].stage == ST_WALKC && L[lane].w.done) lane_closest_done<MATS, MEDIUM>(sc, L[lane]);
+        for (int lane = 0; lane < 64; ++lane)
+            if (in_frame[lane] && L[lane].stage == ST_BACK) lane_back<MATS, MEDIUM>(sc, L[lane]);
+        walk_phase(true, ST_WALKS, ST_FINISH);
+        for (int lane = 0; lane < 64; ++lane)
+            if (in_frame[lane] && L[lane].stage == ST_WALKS && L[lane].w.done) { L[lane].occluded = L[lane].w.found; L[lane].stage = ST_FINISH; }
+        for (int lane = 0; lane < 64; ++lane)
+            if (in_frame[lane] && L[lane].stage == ST_FINISH) lane_finish<MEDIUM>(sc, L[lane]);
     }
-    Lane l;
-    bool off, pooled;
-    lane_unpack<MEDIUM>(P, l, off, pooled);
-    if (!frames_done) return;
-    prt_path_state& r = state[id];
-    r.origin[0] = l.origin.x; r.origin[1] = l.origin.y; r.origin[2] = l.origin.z; r.time = l.t;
-    r.dir[0] = l.dir.x; r.dir[1] = l.dir.y; r.dir[2] = l.dir.z; r.dist = l.time;
-    r.mask[0] = l.mask.x; r.mask[1] = l.mask.y; r.mask[2] = l.mask.z; r.total = l.total;
-    for (int k = 0; k < 4; ++k) r.acc[k] = l.acc[k];
-    r.samples = l.samples;
-    r.diff = (uint16_t)l.diff; r.spec = (uint16_t)l.spec; r.trans = (uint16_t)l.trans; r.scatters = (uint16_t)l.scatters;
-    r.was_specular = l.wasSpecular ? 1 : 0; r.reset = l.reset ? 1 : 0;
-    const float ns = (float)l.samples;
-    float* px = out_rgba + 4 * id;
-    for (int k = 0; k < 4; ++k) px[k] = l.acc[k] / ns;
+    for (int lane = 0; lane < 64; ++lane) {
+        if (!in_frame[lane] || !L[lane].f) continue;
+        const Lane& l = L[lane];
+        prt_path_state& r = state[ids[lane]];
+        r.origin[0] = l.origin.x; r.origin[1] = l.origin.y; r.origin[2] = l.origin.z; r.time = l.t;
+        r.dir[0] = l.dir.x; r.dir[1] = l.dir.y; r.dir[2] = l.dir.z; r.dist = l.time;
+        r.mask[0] = l.mask.x; r.mask[1] = l.mask.y; r.mask[2] = l.mask.z; r.total = l.total;
+        for (int k = 0; k < 4; ++k) r.acc[k] = l.acc[k];
+        r.samples = l.samples;
+        r.diff = (uint16_t)l.diff; r.spec = (uint16_t)l.spec; r.trans = (uint16_t)l.trans; r.scatters = (uint16_t)l.scatters;
+        r.was_specular = l.wasSpecular ? 1 : 0; r.reset = l.reset ? 1 : 0;
+        const float ns = (float)l.samples;
+        float* px = out_rgba + 4 * ids[lane];
+        for (int k = 0; k < 4; ++k) px[k] = l.acc[k] / ns;
+    }
 }
 
 }  // namespace
 
-// same arguments as oracle/pt_oracle.h's pto_job.  Returns 0, or the prt error code of pack_scene.
+// same arguments as oracle/pt_oracle.h's pto_job, plus the schedule.  Returns 0, or the prt error code of pack_scene.
 extern "C" int emu_render(const prt_config* cfg, const prt_scene_desc* desc, const prt_camera* camera, const float* env_rgb, int env_w, int env_h,
                           int width, int full_height, int row0, int rows, int block_rows, int n_parts, int part,
                           uint32_t first_frame, uint32_t n_frames, const int32_t* seed_pairs, prt_path_state* state, float* out_rgba,
-                          uint32_t spp_limit, char* err, int err_len) {
+                          uint32_t spp_limit, uint32_t walk_min_lanes, uint32_t sched_seed, char* err, int err_len) {
     PackedScene ps;
     std::string perr;
     const int rc = pack_scene(*cfg, desc, ps, perr);
@@ -140,20 +160,22 @@ extern "C" int emu_render(const prt_config* cfg, const prt_scene_desc* desc, con
     fa.block_rows = block_rows > 0 ? block_rows : 1; fa.n_parts = n_parts > 0 ? n_parts : 1; fa.part = part;
     fa.first_frame = first_frame; fa.n_frames = n_frames; fa.seed_pairs = seed_pairs; fa.spp_limit = spp_limit;
     fa.unfinished = nullptr; fa.unfinished_host = nullptr; fa.tile_first = 0; fa.tile_stride = 1;
+    fa.walk_min_lanes = walk_min_lanes ? walk_min_lanes : 8;
     constexpr unsigned LD = PRT_MAT_LIGHT | PRT_MAT_DIFF;
     std::vector<unsigned> stack_mem;
-    for (int y = 0; y < rows; ++y)
-        for (int x = 0; x < width; ++x) {
+    const int tiles_x = (width + 7) / 8, tiles_y = (rows + 7) / 8;
+    for (int ty = 0; ty < tiles_y; ++ty)
+        for (int tx = 0; tx < tiles_x; ++tx) {
             // the variant launch_render (pt_kernels.hip) picks
             if (sc.n_sdfs) {
-                if (!sc.has_medium) run_pixel<PT_MATS_SDF, false>(sc, cam, fa, x, y, state, out_rgba, stack_mem);
-                else run_pixel<PT_MATS_SDF, true>(sc, cam, fa, x, y, state, out_rgba, stack_mem);
+                if (!sc.has_medium) run_tile<PT_MATS_SDF, false>(sc, cam, fa, tx, ty, state, out_rgba, sched_seed, stack_mem);
+                else run_tile<PT_MATS_SDF, true>(sc, cam, fa, tx, ty, state, out_rgba, sched_seed, stack_mem);
             } else if (!sc.has_medium) {
-                if (sc.active_mats == LD) run_pixel<LD, false>(sc, cam, fa, x, y, state, out_rgba, stack_mem);
-                else run_pixel<0u, false>(sc, cam, fa, x, y, state, out_rgba, stack_mem);
+                if (sc.active_mats == LD) run_tile<LD, false>(sc, cam, fa, tx, ty, state, out_rgba, sched_seed, stack_mem);
+                else run_tile<0u, false>(sc, cam, fa, tx, ty, state, out_rgba, sched_seed, stack_mem);
             } else {
-                if (sc.active_mats == LD) run_pixel<LD, true>(sc, cam, fa, x, y, state, out_rgba, stack_mem);
-                else run_pixel<0u, true>(sc, cam, fa, x, y, state, out_rgba, stack_mem);
+                if (sc.active_mats == LD) run_tile<LD, true>(sc, cam, fa, tx, ty, state, out_rgba, sched_seed, stack_mem);
+                else run_tile<0u, true>(sc, cam, fa, tx, ty, state, out_rgba, sched_seed, stack_mem);
             }
         }
     return 0;

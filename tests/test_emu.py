@@ -2,9 +2,8 @@
 compiled for the host and run by the wave emulator of tests/emu/pt_emu.cpp, against
   * the golden fixtures produced by the reference build (tests/golden/*.npz), and
   * oracle/pt_oracle.c on ragged sizes,
-bit for bit, through the same pass structure as render_kernel: every pass unparks the pixel's context into a poisoned
-record (lane_unpack), so the list of what survives between passes is checked here, and deep rays take the batch walk's
-path ({node, far child} in, {t, u, v, slot | found} out).  No GPU involved: code generation for gfx950 is what -m gpu checks."""
+bit for bit, under the kernel's default schedule and under RANDOM walk-phase lengths (lanes drift in frame number:
+which lanes walk together must not change a bit).  No GPU involved: code generation for gfx950 is what -m gpu checks."""
 import os
 import sys
 
@@ -38,13 +37,15 @@ def _same(oracle, s0, i0, s1, i1, what):
 
 
 @pytest.mark.parametrize("variant", list(VARIANTS))
-def test_device_code_on_host_matches_reference_golden(prt, oracle, emu, variant):
+@pytest.mark.parametrize("sched", [(8, 0), (1, 0), (8, 12345)])
+def test_device_code_on_host_matches_reference_golden(prt, oracle, emu, variant, sched):
     g = np.load(os.path.join(GOLDEN, variant + ".npz"))
     W, H, frames = int(g["width"]), int(g["height"]), int(g["frames"])
     scene, cfg, cam, env = _scene(prt, variant, W, H)
-    state, img = emu.render(oracle.PATH_STATE_DTYPE, cfg, scene.desc, cam, W, H, prt.seed_pairs(frames), env=env)
+    state, img = emu.render(oracle.PATH_STATE_DTYPE, cfg, scene.desc, cam, W, H, prt.seed_pairs(frames), env=env,
+                            walk_min_lanes=sched[0], sched_seed=sched[1])
     gstate = np.ascontiguousarray(g["state"]).view(oracle.PATH_STATE_DTYPE).reshape(-1)
-    _same(oracle, gstate, g["image"], state, img, variant)
+    _same(oracle, gstate, g["image"], state, img, "%s schedule %s" % (variant, sched))
 
 
 def test_spp_mode_and_batches_on_host(prt, oracle, emu):
@@ -52,11 +53,11 @@ def test_spp_mode_and_batches_on_host(prt, oracle, emu):
     W, H, maxf, spp = int(g["width"]), int(g["height"]), int(g["frames"]), int(g["spp"])
     scene, cfg, cam, env = _scene(prt, "cornell_diffuse", W, H)
     seeds = prt.seed_pairs(maxf)
-    # the "N spp" rule in launches of 32 frames, as prt_render_spp issues them
+    # the "N spp" rule in launches of 32 frames, as prt_render_spp issues them, under a random schedule
     state = img = None
     for f in range(0, maxf, 32):
         state, img = emu.render(oracle.PATH_STATE_DTYPE, cfg, scene.desc, cam, W, H, seeds[2 * f:2 * (f + 32)], first_frame=1 + f,
-                                state=state, img=img, spp_limit=spp)
+                                state=state, img=img, spp_limit=spp, sched_seed=99 + f)
     gstate = np.ascontiguousarray(g["state"]).view(oracle.PATH_STATE_DTYPE).reshape(-1)
     _same(oracle, gstate, g["image"], state, img, "spp golden")
 
@@ -67,9 +68,9 @@ def test_ragged_frame_and_row_blocks_on_host(prt, oracle, emu, variant):
     scene, cfg, cam, env = _scene(prt, variant, W, H)
     seeds = prt.seed_pairs(frames)
     ostate, oimg = oracle.Restatement().render(cfg, scene.desc, cam, W, H, seeds, env=env, threads=8)
-    state, img = emu.render(oracle.PATH_STATE_DTYPE, cfg, scene.desc, cam, W, H, seeds, env=env)
+    state, img = emu.render(oracle.PATH_STATE_DTYPE, cfg, scene.desc, cam, W, H, seeds, env=env, sched_seed=7)
     _same(oracle, ostate, oimg, state, img, variant + " ragged")
     blocks = (4, 3, 1)
-    bstate, bimg = emu.render(oracle.PATH_STATE_DTYPE, cfg, scene.desc, cam, W, H, seeds, env=env, blocks=blocks)
+    bstate, bimg = emu.render(oracle.PATH_STATE_DTYPE, cfg, scene.desc, cam, W, H, seeds, env=env, sched_seed=8, blocks=blocks)
     rows = [r for r in range(H) if (r // blocks[0]) % blocks[1] == blocks[2]]
     assert oracle.images_equal(oimg[rows], bimg), "row blocks differ from the full frame"

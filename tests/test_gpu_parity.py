@@ -427,6 +427,42 @@ def test_dragon_standin_matches_oracle(prt, oracle):
     r.close()
 
 
+@pytest.mark.parametrize("variant", list(VARIANTS))
+@pytest.mark.parametrize("min_lanes", [1, 64])
+def test_schedule_independence(prt, oracle, variant, min_lanes):
+    """the lane machine lets pixels drift in frame number; WHEN a wave ends its walk phases (prt_set_walk_min_lanes:
+    1 = every walk runs to its end, the lock-step schedule; 64 = a phase ends as soon as one lane is done, the most
+    drift) must not change a bit: same state and image as the reference golden, and a render continued under the
+    other schedule equals one rendered in one go"""
+    g = np.load(os.path.join(GOLDEN, variant + ".npz"))
+    W, H, frames = int(g["width"]), int(g["height"]), int(g["frames"])
+    scene, cfg, cam, env, r = _setup(prt, variant, W, H)
+    r.set_walk_min_lanes(min_lanes)
+    r.render_frames(prt.seed_pairs(frames))
+    gstate = np.ascontiguousarray(g["state"]).view(oracle.PATH_STATE_DTYPE).reshape(-1)
+    _assert_same(oracle, gstate, g["image"], r.read_state(), r.read_framebuffer(), "%s min_lanes %d vs golden" % (variant, min_lanes))
+    more = prt.seed_pairs(frames + 20)[2 * frames:]
+    r.set_walk_min_lanes(65 - min_lanes)
+    r.render_frames(more, first_frame=frames + 1)
+    s_mix, i_mix = r.read_state(), r.read_framebuffer()
+    r.close()
+    scene, cfg, cam, env, r2 = _setup(prt, variant, W, H)
+    r2.render_frames(prt.seed_pairs(frames + 20))
+    _assert_same(oracle, r2.read_state().view(oracle.PATH_STATE_DTYPE), r2.read_framebuffer(), s_mix, i_mix, variant + " mixed schedules vs default")
+    r2.close()
+
+
+def test_spp_mode_lockstep_schedule(prt, oracle):
+    g = np.load(os.path.join(GOLDEN, "cornell_diffuse_spp.npz"))
+    W, H, maxf, spp = int(g["width"]), int(g["height"]), int(g["frames"]), int(g["spp"])
+    scene, cfg, cam, env, r = _setup(prt, "cornell_diffuse", W, H)
+    r.set_walk_min_lanes(1)
+    r.render_spp(spp, prt.seed_pairs(maxf))
+    gstate = np.ascontiguousarray(g["state"]).view(oracle.PATH_STATE_DTYPE).reshape(-1)
+    _assert_same(oracle, gstate, g["image"], r.read_state(), r.read_framebuffer(), "lock-step spp golden")
+    r.close()
+
+
 def test_full_size_frame_against_oracle_strips_and_properties(prt, oracle):
     """BASELINE config 2 at its real size (1920x1080): the oracle renders three 4-row strips of the frame
     (global pixel coordinates) and must match the GPU's full-frame pixels bit for bit; plus the
