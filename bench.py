@@ -11,16 +11,18 @@ every pixel has finished its S-th path (the reference's "N spp" in its own work 
 SURVEY.md s8d).  Inputs (scene, BVH, camera, seed table) are resident in HBM before the timed
 region.  With N > 1 the frame is split into interleaved row blocks, one set per rank (pixels are
 independent; seeds use global pixel coordinates, so the union is bit-identical to the 1-GPU
-image of that frame), and ONE RCCL reduce(sum) of the zero-padded full-size framebuffer per step
-merges them on rank 0 -- inside the timed region.
+image of that frame), and ONE RCCL collective per step -- an all-gather of every rank's rows --
+puts the framebuffer together on rank 0, inside the timed region.  By default rank 0 then renders
+the whole frame alone (untimed) and the JSON line says whether the merged frame equals it bit for bit.
 
-Scaling.  Default "weak": per-GPU work is fixed -- the N-GPU frame has N x the pixels of the base
-frame (same scene, camera and aspect, both dimensions x sqrt(N): 1920x1080, 2720x1530, 3840x2160,
-5424x3051), so every rank renders ~2.07 M pixels x spp as the 1-GPU run does.  `--scaling strong`
-keeps the base frame and splits it N ways instead; at 1080p that stops scaling early for a
+Scaling.  Default "strong": the FIXED base frame (BASELINE config 2: 1920x1080, 1024 spp) split N
+ways, so the N = 1 / 2 / 4 / 8 runs measure the same job.  At 1080p that stops scaling early for a
 structural reason measured in DESIGN.md s5: the frame has 32 400 waves of pixels, eight MI355X hold
 32 768 resident waves, so the run time falls to the sequential chain of the slowest tile
-(spp x path length segments, one after the other), not to work / N.
+(spp x path length segments, one after the other), not to work / N.  With N = 8 the run adds
+BASELINE config 5 -- the 871 k-triangle stand-in at 3840x2160, 8-way split -- as `config5`.
+`--scaling weak` (opt-in) fixes the per-GPU work instead: the N-GPU frame has N x the pixels of the
+base frame (both dimensions x sqrt(N): 2720x1530, 3840x2160, 5424x3051).
 
 The JSON line also carries
   roofline      the dominant kernel (render_kernel) priced in ALGORITHMIC bytes: 240 B per pixel
@@ -49,6 +51,106 @@ ALGO_BYTES_PER_SEGMENT = 240
 HBM_PEAK_GBPS = 8000.0                # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def run_workload(prt, par, torch, dist, np, a, world, rank, local_rank, scene_name, base_w, base_h, spp, env_name, phase, scaling, steps, warmup, verify):
+    """times `steps` renders of one workload on this rank's share of the frame; returns the measurements (rank 0: all of them)"""
+    W, H = base_w, base_h
+    if world > 1 and scaling == "weak":
+        W = int(round(base_w * world ** 0.5 / 16.0)) * 16
+        H = int(round(base_h * W / float(base_w)))
+    if "dragon" in scene_name:
+        if rank == 0:
+            prt.ensure_dragon_standin()                    # 62 MB, generated once; the other ranks wait for the file
+        if world > 1:
+            dist.barrier()
+    scene = prt.HostScene(scene_name)
+    cfg = scene.config()
+    cfg.phase_function = {"isotropic": 0, "hg": 1, "rayleigh": 2}[phase]
+    cam = prt.default_camera(W, H)
+    max_frames = max(64, spp * max(cfg.max_bounces, 8) + 64)      # a path has at most max_bounces (+1) segments
+    seeds = prt.seed_pairs(max_frames)
+
+    r = prt.Renderer(cfg, device=local_rank)
+    r.upload_scene(scene)
+    if env_name == "sky":
+        r.upload_envmap(prt.make_sky(1024, 512))
+    r.set_camera(cam)
+    # all GPU work of a step -- libprt's launches, the device-to-device copy of the rows, torch's merge -- is ordered
+    # on ONE explicit stream (torch's default stream is the null handle, which libprt takes as "use your own")
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    r.set_stream(stream.cuda_stream)
+    if world == 1:
+        r.resize(W, H)
+        my_rows = None
+    else:
+        my_rows = par.rows_of_rank(H, world, rank)
+        r.set_row_blocks(W, H, par.BLOCK_ROWS, world, rank)
+        tile = torch.zeros((par.max_rows_per_rank(H, world), W, 4), dtype=torch.float32, device="cuda")
+
+    merged = [None]
+    m = {"kernel_ms": 0.0, "kernel_sum_ms": 0.0, "launches": 0, "concurrent": 1}
+
+    def step(timed):
+        r.reset()
+        r.render_spp(spp, seeds)
+        if world > 1:
+            r.copy_framebuffer_to_device(tile.data_ptr())          # this rank's rows (the padding rows stay zero)
+            merged[0] = par.merge_on_rank0(tile, H, W, world, dist)
+        if timed:
+            st = r.stats()
+            m["kernel_ms"] += st.kernel_ms
+            m["kernel_sum_ms"] += st.kernel_sum_ms
+            m["launches"] += st.launches
+            m["concurrent"] = st.concurrent
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step(False)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(True)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    verified = None
+    if verify and world > 1:
+        torch.cuda.synchronize()
+        if rank == 0:
+            r1 = prt.Renderer(cfg, device=local_rank)
+            r1.upload_scene(scene)
+            if env_name == "sky":
+                r1.upload_envmap(prt.make_sky(1024, 512))
+            r1.set_camera(cam)
+            r1.resize(W, H)
+            r1.render_spp(spp, seeds)
+            alone = r1.read_framebuffer()
+            r1.close()
+            verified = bool(np.array_equal(alone.view(np.uint32), merged[0].cpu().numpy().view(np.uint32)))
+        dist.barrier()
+
+    counts = r.counts(spp)
+    seg = torch.tensor([float(counts.segments), float(counts.samples)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(seg, op=dist.ReduceOp.SUM)
+    r.close()
+    torch.cuda.set_stream(torch.cuda.default_stream())
+    steps_ = max(steps, 1)
+    own_segments = float(counts.segments)
+    return {"W": W, "H": H, "spp": spp, "dt": dt, "msamples": W * H * spp * steps_ / dt / 1e6, "ms_per_step": dt / steps_ * 1e3,
+            "total_segments": float(seg[0]), "total_samples": float(seg[1]), "own_segments": own_segments, "verified": verified,
+            "kernel_ms": m["kernel_ms"], "kernel_sum_ms": m["kernel_sum_ms"], "launches": m["launches"], "concurrent": m["concurrent"],
+            "max_bounces": cfg.max_bounces}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -60,11 +162,13 @@ def main():
     ap.add_argument("--scene", default="cornell_diffuse.json")
     ap.add_argument("--env", default="", choices=["", "sky"], help="sky = the procedural 1024x512 HDR stand-in (configs 3, 4)")
     ap.add_argument("--phase", default="isotropic", choices=["isotropic", "hg", "rayleigh"], help="phase function of the global medium (config 4)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="N > 1: weak = N x the pixels (frame x sqrt(N) per dimension), strong = the base frame split N ways")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: strong (default) = the FIXED base frame split N ways; weak = N x the pixels (frame x sqrt(N) per dimension)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--verify", action="store_true",
-                    help="N > 1: after the timed steps rank 0 renders the whole frame alone and compares it bit for bit with the merged one")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="N > 1: skip the check that rank 0's merged frame equals, bit for bit, the frame one GPU renders alone")
+    ap.add_argument("--config5-spp", type=int, default=256,
+                    help="N = 8 only: spp of the extra BASELINE config 5 run (871 k-triangle stand-in, 3840x2160, 8-way split); 0 = skip")
     a = ap.parse_args()
 
     import numpy as np
@@ -93,133 +197,50 @@ def main():
         else:
             dist.init_process_group(backend=backend)
 
+    # one rank builds (the others would write the same object files at the same time), everybody waits
+    if not os.path.exists(os.path.join(ROOT, PKG_NAME, "libprt.so")):
+        if rank == 0:
+            import __graft_entry__ as ge
+            ge.build()
+    if world > 1:
+        dist.barrier()
     prt = importlib.import_module(PKG_NAME)
     par = importlib.import_module(PKG_NAME + ".parallel")
-    import __graft_entry__ as ge
-    if not os.path.exists(os.path.join(ROOT, PKG_NAME, "libprt.so")):
-        ge.build()
 
-    W, H, spp = a.width, a.height, a.spp
-    if world > 1 and a.scaling == "weak":
-        W = int(round(a.width * world ** 0.5 / 16.0)) * 16
-        H = int(round(a.height * W / float(a.width)))
-    if "dragon" in a.scene:
-        prt.ensure_dragon_standin()
-    scene = prt.HostScene(a.scene)
-    cfg = scene.config()
-    cfg.phase_function = {"isotropic": 0, "hg": 1, "rayleigh": 2}[a.phase]
-    cam = prt.default_camera(W, H)
-    max_frames = max(64, spp * max(cfg.max_bounces, 8) + 64)      # a path has at most max_bounces (+1) segments
-    seeds = prt.seed_pairs(max_frames)
-
-    r = prt.Renderer(cfg, device=local_rank)
-    r.upload_scene(scene)
-    if a.env == "sky":
-        r.upload_envmap(prt.make_sky(1024, 512))
-    r.set_camera(cam)
-    # all GPU work of a step -- libprt's launches, the device-to-device copy of the rows, torch's merge -- is ordered
-    # on ONE explicit stream (torch's default stream is the null handle, which libprt takes as "use your own")
-    stream = torch.cuda.Stream()
-    torch.cuda.set_stream(stream)
-    r.set_stream(stream.cuda_stream)
-    if world == 1:
-        r.resize(W, H)
-        my_rows = None
-    else:
-        my_rows = par.rows_of_rank(H, world, rank)
-        r.set_row_blocks(W, H, par.BLOCK_ROWS, world, rank)
-        tile = torch.zeros((len(my_rows), W, 4), dtype=torch.float32, device="cuda")
-
-    merged = [None]
-    kernel_ms = 0.0          # wall time of the GPU work of the timed steps (HIP events around all of it)
-    kernel_sum_ms = 0.0      # sum of the durations of the individual launches (HIP events around each)
-    launches = 0
-    concurrent = 1
-
-    def step(timed):
-        nonlocal kernel_ms, kernel_sum_ms, launches, concurrent
-        r.reset()
-        r.render_spp(spp, seeds)
-        if world > 1:
-            r.copy_framebuffer_to_device(tile.data_ptr())
-            merged[0] = par.merge_on_rank0(tile, my_rows, H, W, dist)
-        if timed:
-            st = r.stats()
-            kernel_ms += st.kernel_ms
-            kernel_sum_ms += st.kernel_sum_ms
-            launches += st.launches
-            concurrent = st.concurrent
-
-    def sync():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(a.warmup):
-        step(False)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step(True)
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-
-    verified = None
-    if a.verify and world > 1:
-        torch.cuda.synchronize()
-        if rank == 0:
-            r1 = prt.Renderer(cfg, device=local_rank)
-            r1.upload_scene(scene)
-            if a.env == "sky":
-                r1.upload_envmap(prt.make_sky(1024, 512))
-            r1.set_camera(cam)
-            r1.resize(W, H)
-            r1.render_spp(spp, seeds)
-            alone = r1.read_framebuffer()
-            r1.close()
-            verified = bool(np.array_equal(alone.view(np.uint32), merged[0].cpu().numpy().view(np.uint32)))
-        dist.barrier()
-
-    counts = r.counts(spp)
-    seg = torch.tensor([float(counts.segments), float(counts.samples), kernel_ms, float(launches)], dtype=torch.float64, device="cuda")
-    if world > 1:
-        seg_sum = seg.clone()
-        dist.all_reduce(seg_sum, op=dist.ReduceOp.SUM)
-        seg_max = seg.clone()
-        dist.all_reduce(seg_max, op=dist.ReduceOp.MAX)
-        total_segments, total_samples = float(seg_sum[0]), float(seg_sum[1])
-        kernel_ms_max = float(seg_max[2])
-    else:
-        total_segments, total_samples = float(seg[0]), float(seg[1])
-        kernel_ms_max = kernel_ms
+    verify = world > 1 and not a.no_verify
+    res = run_workload(prt, par, torch, dist, np, a, world, rank, local_rank, a.scene, a.width, a.height, a.spp, a.env, a.phase,
+                       a.scaling, a.steps, a.warmup, verify)
+    # BASELINE config 5 is defined on 8 GPUs: the 871 k-triangle stand-in at 3840x2160, 8-way tile split + framebuffer merge
+    res5 = None
+    if (world == 8 or (world > 1 and os.environ.get("PRT_BENCH_CONFIG5") == "1")) and a.config5_spp > 0 and a.scene == "cornell_diffuse.json":
+        res5 = run_workload(prt, par, torch, dist, np, a, world, rank, local_rank, "cornell_dragon.json", 3840, 2160, a.config5_spp, "", "isotropic",
+                            "strong", 1, 1, verify)
 
     if rank == 0:
+        W, H, spp = res["W"], res["H"], res["spp"]
         steps = max(a.steps, 1)
-        msamples = W * H * spp * steps / dt / 1e6
+        kernel_ms, kernel_sum_ms, launches, concurrent = res["kernel_ms"], res["kernel_sum_ms"], res["launches"], res["concurrent"]
+        total_segments, total_samples, own_segments = res["total_segments"], res["total_samples"], res["own_segments"]
         # rank-0 kernel: its own segments per step over its own kernel time
-        own_segments = float(counts.segments)
         achieved = ALGO_BYTES_PER_SEGMENT * own_segments * steps / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("workload") == "%dx%d_%dspp_%s" % (a.width, a.height, spp, a.scene):   # per launch of the base frame = per rank
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        for tname in ("r02_traffic.json", "r01_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", tname)
+            if traffic is None and os.path.exists(tpath):
+                try:
+                    tj = json.load(open(tpath))
+                    if world == 1 and tj.get("workload") == "%dx%d_%dspp_%s" % (a.width, a.height, spp, a.scene):   # per launch of the whole frame
+                        traffic = tj.get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
         out = {
             "metric": "Msamples/s (width x height x spp / s) at %dx%d" % (a.width, a.height),
-            "value": round(msamples, 3),
+            "value": round(res["msamples"], 3),
             "unit": "Msamples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(dt / steps * 1e3, 3),
+            "ms_per_step": round(res["ms_per_step"], 3),
             "higher_is_better": True,
-            "scaling": a.scaling if world > 1 else "weak",
+            "scaling": a.scaling if world > 1 else "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -230,7 +251,7 @@ def main():
                        "mean_path_length": round(total_segments / max(total_samples, 1.0), 4),
                        "segments_per_step": total_segments,
                        "base_frame": "%dx%d" % (a.width, a.height),
-                       "parallelism": "single GPU" if world == 1 else "%s scaling: %dx%d frame in interleaved 16-row blocks over %d ranks + 1 RCCL reduce" % (a.scaling, W, H, world)},
+                       "parallelism": "single GPU" if world == 1 else "%s scaling: %dx%d frame in interleaved 16-row blocks over %d ranks + 1 RCCL all-gather of the rows per step" % (a.scaling, W, H, world)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                          "kernel": "render_kernel", "algorithmic_bytes_per_segment": ALGO_BYTES_PER_SEGMENT,
@@ -242,15 +263,21 @@ def main():
                                  "launches x avg_launch_ms ~ %d x kernel_wall_ms" % (concurrent, concurrent),
                          "gsegments_per_s": round(own_segments * steps / (kernel_ms * 1e-3) / 1e9, 4) if kernel_ms > 0 else 0.0},
         }
-        if verified is not None:
-            out["config"]["merged_frame_equals_single_gpu_render"] = verified
+        if res["verified"] is not None:
+            out["config"]["merged_frame_equals_single_gpu_render"] = res["verified"]
+        if res5 is not None:
+            out["config5"] = {"workload": "scenes/cornell_dragon (871 k-triangle stand-in) 3840x2160 %dspp, %d x MI355X tile split + RCCL framebuffer merge "
+                                          "(BASELINE config 5 at a reduced spp: the full 8192 spp is %d x this work)" % (res5["spp"], world, 8192 // max(res5["spp"], 1)),
+                              "value": round(res5["msamples"], 3), "unit": "Msamples/s", "ms_per_step": round(res5["ms_per_step"], 3),
+                              "mean_path_length": round(res5["total_segments"] / max(res5["total_samples"], 1.0), 4),
+                              "gsegments_per_s_all_gpus": round(res5["total_segments"] / (res5["dt"]) / 1e9, 4),
+                              "merged_frame_equals_single_gpu_render": res5["verified"]}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(prt, a)
             ref = cpu_reference_build(prt, a)
             if ref is not None:
                 out["cpu_reference_build"] = ref
         print(json.dumps(out))
-    r.close()
     if world > 1:
         dist.destroy_process_group()
 

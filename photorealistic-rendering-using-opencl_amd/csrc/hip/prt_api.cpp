@@ -52,6 +52,8 @@ struct prt_ctx {
     hipEvent_t sub_ev0[MAX_SUB][2] = {};          // its start (prt_render_spp times every launch)
     hipEvent_t fork_ev = nullptr;
     unsigned long long* h_unfinished = nullptr;   // pinned, [MAX_SUB][2]: written by the last wave of a launch
+    unsigned frames_per_launch = 128;              // frames a launch of render_kernel covers (PRT_FRAMES_PER_LAUNCH); measured on
+                                                   // MI355X: 32 -> 3.82, 64 -> 3.95, 128 -> 4.01 G segments/s, 256 the same
     uint32_t walk_min_lanes = 4;                   // FrameArgs::walk_min_lanes (prt_set_walk_min_lanes, PRT_WALK_MIN_LANES)
     prt_stats stats{};
     std::string err;
@@ -112,6 +114,7 @@ extern "C" int prt_create(int device, const prt_config* cfg, prt_ctx** out) {
             return PRT_ERR_HIP;
         }
     c->stream = c->own_stream;
+    if (const char* ev = std::getenv("PRT_FRAMES_PER_LAUNCH")) { const int k = std::atoi(ev); if (k >= 1) c->frames_per_launch = (unsigned)k; }
     if (const char* ev = std::getenv("PRT_WALK_MIN_LANES")) { const int k = std::atoi(ev); if (k >= 1 && k <= 64) c->walk_min_lanes = (uint32_t)k; }
     *out = c;
     return PRT_OK;
@@ -296,16 +299,6 @@ static int ensure_seeds(prt_ctx* c, const int32_t* seed_pairs, size_t n_frames) 
     return PRT_OK;
 }
 
-static unsigned frames_per_launch() {
-    static unsigned v = 0;
-    if (!v) {
-        const char* e = std::getenv("PRT_FRAMES_PER_LAUNCH");
-        v = e ? (unsigned)std::atoi(e) : 128u;   // measured on MI355X: 32 -> 3.82, 64 -> 3.95, 128 -> 4.01 G segments/s
-        if (v == 0) v = 128u;
-    }
-    return v;
-}
-
 static int ready(prt_ctx* c, const char* who) {
     if (!c->have_scene) return fail(c, PRT_ERR_NOT_READY, std::string(who) + ": no scene uploaded");
     if (!c->have_cam) return fail(c, PRT_ERR_NOT_READY, std::string(who) + ": no camera set");
@@ -351,7 +344,7 @@ extern "C" int prt_render_frames(prt_ctx* c, uint32_t first_frame, uint32_t n_fr
     c->stats.launches = 0; c->stats.frames = 0; c->stats.kernel_ms = 0.0; c->stats.kernel_sum_ms = 0.0; c->stats.concurrent = 1;
     if (!n_frames) return PRT_OK;
     if ((rc = ensure_seeds(c, seed_pairs, n_frames))) return rc;
-    const unsigned step = frames_per_launch();
+    const unsigned step = c->frames_per_launch;
     const int K = sub_parts(c);
     c->stats.concurrent = (uint32_t)K;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
@@ -381,7 +374,7 @@ extern "C" int prt_render_spp(prt_ctx* c, uint32_t spp, uint32_t max_frames, con
     HIPCHK(c, hipSetDevice(c->device));
     c->stats.launches = 0; c->stats.frames = 0; c->stats.kernel_ms = 0.0; c->stats.kernel_sum_ms = 0.0; c->stats.concurrent = 1;
     if ((rc = ensure_seeds(c, seed_pairs, max_frames))) return rc;
-    const unsigned step = frames_per_launch();
+    const unsigned step = c->frames_per_launch;
     const int K = sub_parts(c);
     c->stats.concurrent = (uint32_t)K;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));

@@ -61,6 +61,8 @@ public:
 private:
     const std::string& s;
     size_t p;
+    int depth = 0;                                 // nesting of objects / arrays: bounded, the parser recurses
+    struct Nest { int& d; explicit Nest(int& dd) : d(dd) { ++d; } ~Nest() { --d; } };
     [[noreturn]] void fail(const char* msg) {
         throw std::runtime_error(std::string("json: ") + msg + " at offset " + std::to_string(p));
     }
@@ -78,6 +80,8 @@ private:
         return number();
     }
     Value object() {
+        Nest nest(depth);
+        if (depth > 64) fail("nesting deeper than 64 levels");
         Value v; v.kind = Value::Object;
         ++p; ws();
         if (p < s.size() && s[p] == '}') { ++p; return v; }
@@ -97,6 +101,8 @@ private:
         return v;
     }
     Value array() {
+        Nest nest(depth);
+        if (depth > 64) fail("nesting deeper than 64 levels");
         Value v; v.kind = Value::Array;
         ++p; ws();
         if (p < s.size() && s[p] == ']') { ++p; return v; }

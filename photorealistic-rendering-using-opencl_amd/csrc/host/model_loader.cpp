@@ -51,6 +51,8 @@ bool ModelLoader::load_obj(const std::string& path) {
         if (s[0] == 'v' && (s[1] == ' ' || s[1] == '\t')) {
             float3 p; char* e;
             p.x = strtof(s + 2, &e); p.y = strtof(e, &e); p.z = strtof(e, &e);
+            // strtof accepts "nan" / "inf": a non-finite position would make the BVH builder's ordering undefined
+            if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) { err_ = "non-finite vertex position in '" + path + "'"; return false; }
             pos.push_back(p);
         } else if (s[0] == 'v' && s[1] == 'n' && (s[2] == ' ' || s[2] == '\t')) {
             float3 p; char* e;
@@ -140,6 +142,13 @@ bool ModelLoader::load_soup(const std::string& path) {
     f.read(magic, 8);
     f.read(reinterpret_cast<char*>(&n), 4);
     if (!f || std::memcmp(magic, "PRTMESH1", 8) != 0) { err_ = "bad soup header in '" + path + "'"; return false; }
+    {   // the header's triangle count against the file itself, BEFORE it sizes any allocation (a damaged count asks for ~300 GB)
+        const std::streampos here = f.tellg();
+        f.seekg(0, std::ios::end);
+        const std::streamoff size = f.tellg();
+        f.seekg(here);
+        if (size < 12 || (uint64_t)n * 72u + 12u > (uint64_t)size) { err_ = "truncated soup '" + path + "' (header announces more triangles than the file holds)"; return false; }
+    }
     Mesh mesh;
     mesh.faces.resize(n);
     std::vector<float> buf((size_t)n * 18);
@@ -148,6 +157,7 @@ bool ModelLoader::load_soup(const std::string& path) {
     for (uint32_t i = 0; i < n; ++i)
         for (int c = 0; c < 3; ++c) {
             const float* p = &buf[(size_t)i * 18 + c * 6];
+            if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2])) { err_ = "non-finite vertex position in '" + path + "'"; return false; }
             mesh.faces[i].points[c].pos = {p[0], p[1], p[2]};
             mesh.faces[i].points[c].nor = {p[3], p[4], p[5]};
         }

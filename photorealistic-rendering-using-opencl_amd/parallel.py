@@ -2,8 +2,10 @@
 
 The path shards with no data-path exchange: every pixel is independent (its state, RNG keying and
 output depend only on its own global coordinates and the frame number), so each rank renders its
-own rows and ONE collective at the end puts the framebuffer together on rank 0 -- a sum of
-zero-padded full-size buffers (`torch.distributed.reduce`, RCCL over xGMI when the backend is nccl).
+own rows and ONE collective at the end puts the framebuffer together on rank 0: an all-gather of
+the ranks' row tiles (RCCL over xGMI when the backend is nccl), scattered into place by row index.
+Moving the rows themselves is lossless for every bit pattern (a sum of zero-padded frames would turn
+-0.0 into +0.0) and moves each pixel once instead of N times.
 Rows are dealt in interleaved blocks of 16 (prt_set_row_blocks) so the ranks get equal shares of
 the expensive middle of the picture.
 """
@@ -18,13 +20,21 @@ def rows_of_rank(height, world, rank, block=BLOCK_ROWS):
     return rows[(rows // block) % world == rank]
 
 
-def merge_on_rank0(tile, rows, height, width, dist, device=None):
-    """tile: (len(rows), width, 4) float32 torch tensor with this rank's rows.  Returns the full
-    (height, width, 4) tensor; only rank 0's copy is complete (reduce, not all-reduce)."""
+def max_rows_per_rank(height, world, block=BLOCK_ROWS):
+    return max(len(rows_of_rank(height, world, r, block)) for r in range(world))
+
+
+def merge_on_rank0(tile, height, width, world, dist):
+    """tile: (max_rows_per_rank, width, 4) float32 torch tensor, this rank's rows first (padding rows are ignored).
+    Returns the full (height, width, 4) tensor."""
     import torch
-    full = torch.zeros((height, width, 4), dtype=torch.float32, device=tile.device if device is None else device)
-    idx = torch.as_tensor(np.asarray(rows), dtype=torch.long, device=full.device)
-    full.index_copy_(0, idx, tile.to(full.device))
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.reduce(full, dst=0, op=dist.ReduceOp.SUM)
+    if world == 1 or dist is None or not dist.is_initialized():
+        return tile[:height]
+    pieces = [torch.empty_like(tile) for _ in range(world)]
+    dist.all_gather(pieces, tile.contiguous())
+    full = torch.empty((height, width, 4), dtype=torch.float32, device=tile.device)
+    for r in range(world):
+        rows = rows_of_rank(height, world, r)
+        idx = torch.as_tensor(np.asarray(rows), dtype=torch.long, device=tile.device)
+        full.index_copy_(0, idx, pieces[r][:len(rows)])
     return full

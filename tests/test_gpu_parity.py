@@ -152,8 +152,9 @@ def test_interleaved_row_blocks_union_equals_full_frame(prt, oracle):
 
 def test_device_side_merge_of_row_block_parts_with_torch(prt, oracle):
     """the multi-GPU merge path of bench.py on one GPU: every part copies its rows device-to-device into a torch
-    tensor (prt_copy_framebuffer_to_device), the parts are summed into zero-padded full frames (parallel.merge_on_rank0
-    without a process group) -- both with the context's own stream and with a torch stream handed to prt_set_stream"""
+    tensor (prt_copy_framebuffer_to_device) and the rows are scattered into the full frame by row index (what
+    parallel.merge_on_rank0 does with the gathered tiles) -- both with the context's own stream and with a torch stream
+    handed to prt_set_stream"""
     import torch
     par = importlib.import_module(PKG_NAME + ".parallel")
     W, H, frames, parts = 72, 50, 40, 3
@@ -180,7 +181,7 @@ def test_device_side_merge_of_row_block_parts_with_torch(prt, oracle):
             rp.copy_framebuffer_to_device(tile.data_ptr())
             if stream is not None:
                 torch.cuda.current_stream().wait_stream(stream)
-            total += par.merge_on_rank0(tile, rows, H, W, None)
+            total.index_copy_(0, torch.as_tensor(np.asarray(rows), dtype=torch.long, device="cuda"), tile)
             torch.cuda.synchronize()
             rp.close()
         assert oracle.images_equal(full, total.cpu().numpy()), "merged parts differ (torch stream: %s)" % use_torch_stream
@@ -262,6 +263,61 @@ def test_errors_are_reported_not_fatal(prt):
     boxed = prt.HostScene(json.dumps(doc), text=True)
     with pytest.raises(prt.PrtError, match="box"):
         prt.Renderer(boxed.config(), device=0)
+
+
+def test_failed_reallocation_leaves_the_context_not_ready(prt, oracle):
+    """a resize that cannot be satisfied must leave the context NOT READY (never "ready" with freed planes: the next
+    launch would fault the GPU), and a later valid resize must bring it back; a rejected scene upload leaves the old
+    scene in place"""
+    g = np.load(os.path.join(GOLDEN, "cornell_diffuse.npz"))
+    W, H, frames = int(g["width"]), int(g["height"]), int(g["frames"])
+    scene, cfg, cam, env, r = _setup(prt, "cornell_diffuse", W, H)
+    seeds = prt.seed_pairs(frames)
+    with pytest.raises(prt.PrtError):
+        r.resize(1 << 20, 1 << 20)                  # 6 planes x 16 TiB
+    with pytest.raises(prt.PrtError, match="no frame size"):
+        r.render_frames(seeds)                      # PRT_ERR_NOT_READY, no launch
+    with pytest.raises(prt.PrtError):
+        r.read_framebuffer()
+    r.resize(W, H)
+    # a scene the packer refuses (light index out of range) must not disturb the uploaded one
+    bad_cfg = prt.Config.from_buffer_copy(bytes(cfg))
+    bad_cfg.light_indices[0] = 1000
+    r_bad = prt.Renderer(bad_cfg, device=0)
+    with pytest.raises(prt.PrtError, match="light index"):
+        r_bad.upload_scene(scene)
+    with pytest.raises(prt.PrtError, match="no scene"):
+        r_bad.render_frames(seeds)
+    r_bad.close()
+    desc = prt.SceneDesc.from_buffer_copy(bytes(scene.desc))
+    desc.object_count[7] = desc.object_count[7] + 1          # counts no longer add up
+    with pytest.raises(prt.PrtError, match="add up"):
+        r.upload_scene(desc)
+    r.render_frames(seeds)
+    gstate = np.ascontiguousarray(g["state"]).view(oracle.PATH_STATE_DTYPE).reshape(-1)
+    _assert_same(oracle, gstate, g["image"], r.read_state(), r.read_framebuffer(), "after failed resize / upload")
+    r.close()
+
+
+@pytest.mark.parametrize("streams", ["1", "2"])
+def test_spp_frame_budget_exhausted_then_render_again(prt, oracle, streams, monkeypatch):
+    """prt_render_spp that runs out of max_frames reports PRT_ERR_NOT_READY with every internal stream joined and the
+    launch counters clean: the same context must render correctly afterwards"""
+    monkeypatch.setenv("PRT_STREAMS", streams)
+    monkeypatch.setenv("PRT_FRAMES_PER_LAUNCH", "8")
+    gs = np.load(os.path.join(GOLDEN, "cornell_diffuse_spp.npz"))
+    W, H, maxf, spp = int(gs["width"]), int(gs["height"]), int(gs["frames"]), int(gs["spp"])
+    scene, cfg, cam, env, r = _setup(prt, "cornell_diffuse", W, H)
+    with pytest.raises(prt.PrtError, match="max_frames"):
+        r.render_spp(spp, prt.seed_pairs(12))       # 12 frames cannot finish 6 paths per pixel
+    st = r.read_state()
+    assert (st["samples"] >= 1).all() and not (st["samples"] == spp).all()
+    r.reset()
+    used = r.render_spp(spp, prt.seed_pairs(maxf))
+    assert 0 < used <= maxf
+    sstate = np.ascontiguousarray(gs["state"]).view(oracle.PATH_STATE_DTYPE).reshape(-1)
+    _assert_same(oracle, sstate, gs["image"], r.read_state(), r.read_framebuffer(), "spp after an exhausted call, streams=%s" % streams)
+    r.close()
 
 
 @pytest.mark.parametrize("streams", ["1", "2", "3", "4"])

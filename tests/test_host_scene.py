@@ -180,3 +180,28 @@ def test_malformed_scene_is_an_error_not_a_crash(prt):
     for text in ("{", '{"scen":{}}', '{"scene":{"obj":{"path":"missing_model.obj"}}}'):
         with pytest.raises(prt.PrtError):
             prt.HostScene(text, text=True)
+
+
+def test_hostile_inputs_are_refused_before_they_cost_memory(prt, tmp_path):
+    """a damaged .prtmesh header must not size an allocation (300 GB for n = 2^32 - 1), deeply nested JSON must not
+    overflow the stack, and `nan` / `inf` vertex positions (strtof accepts them) must not reach the BVH builder"""
+    lib = prt.load_library()
+    err = C.create_string_buffer(256)
+    soup = tmp_path / "lie.prtmesh"
+    soup.write_bytes(b"PRTMESH1" + struct.pack("<I", 0xFFFFFFFF) + bytes(72 * 3))
+    text = '{"scene":{"obj":{"path":"lie.prtmesh","material":{"type":1}},"spheres":[{"pos":[0,3,0],"radius":0.5,"material":{"color":[5,5,5],"type":0}}]}}'
+    with pytest.raises(prt.PrtError, match="truncated soup"):
+        prt.HostScene(text, models_dir=str(tmp_path), text=True)
+    with pytest.raises(prt.PrtError, match="nesting"):
+        prt.HostScene("[" * 100000, text=True)
+    with pytest.raises(prt.PrtError, match="nesting"):
+        prt.HostScene('{"a":' * 100 + "1" + "}" * 100, text=True)
+    for bad in ("nan", "inf", "-inf"):
+        obj = tmp_path / ("bad_%s.obj" % bad.strip("-"))
+        obj.write_text("v 0 0 0\nv 1 0 %s\nv 1 1 0\nf 1 2 3\n" % bad)
+        assert lib.prth_convert_model(str(obj).encode(), str(tmp_path / "o.prtmesh").encode(), err, 256) != 0
+        assert b"non-finite" in err.value
+    nan_soup = tmp_path / "nan.prtmesh"
+    nan_soup.write_bytes(b"PRTMESH1" + struct.pack("<I", 1) + np.array([0, 0, 0, 0, 0, 1, 1, np.nan, 0, 0, 0, 1, 1, 1, 0, 0, 0, 1], dtype=np.float32).tobytes())
+    with pytest.raises(prt.PrtError, match="non-finite"):
+        prt.HostScene(text.replace("lie.prtmesh", "nan.prtmesh"), models_dir=str(tmp_path), text=True)

@@ -1,6 +1,6 @@
 """N > 1: the frame partition and the framebuffer merge, with world_size 2 over gloo on the CPU.
 The per-rank renderer here is the CPU oracle (this container has no GPU); on the GPU the same
-partition (prt_set_row_blocks) and the same merge (parallel.merge_on_rank0 -> one reduce) carry
+partition (prt_set_row_blocks) and the same merge (parallel.merge_on_rank0 -> one all-gather) carry
 libprt's framebuffer, which tests/test_gpu_parity.py checks tile by tile."""
 import importlib
 import os
@@ -33,7 +33,10 @@ def _worker(rank, world, port, out_path):
     rows = par.rows_of_rank(H, world, rank)
     _, tile = O.Restatement().render(cfg, scene.desc, cam, W, H, seeds, blocks=(par.BLOCK_ROWS, world, rank), threads=2)
     assert tile.shape[0] == len(rows)
-    full = par.merge_on_rank0(torch.from_numpy(tile), rows, H, W, dist)
+    tile[0, 0, 3] = -0.0                                   # a bit pattern a sum of zero-padded frames would lose
+    padded = torch.zeros((par.max_rows_per_rank(H, world), W, 4), dtype=torch.float32)
+    padded[:len(rows)] = torch.from_numpy(tile)
+    full = par.merge_on_rank0(padded, H, W, world, dist)
     dist.barrier()
     if rank == 0:
         np.save(out_path, full.numpy())
@@ -50,4 +53,7 @@ def test_two_ranks_reproduce_the_single_rank_image(prt, oracle, tmp_path):
     merged = np.load(out)
     scene = prt.HostScene("cornell_coat.json")
     _, single = oracle.Restatement().render(scene.config(), scene.desc, prt.default_camera(W, H), W, H, prt.seed_pairs(FRAMES), threads=4)
-    assert oracle.images_equal(single, merged)          # x + 0 == x exactly: the reduce of zero-padded tiles is lossless
+    par = importlib.import_module(PKG_NAME + ".parallel")
+    for rk in range(WORLD):
+        single[par.rows_of_rank(H, WORLD, rk)[0], 0, 3] = -0.0        # what the workers planted
+    assert np.array_equal(single.view(np.uint32), merged.view(np.uint32))   # the rows themselves travel: every bit pattern survives
