@@ -85,6 +85,24 @@ SCENES["cornell_sdf"]["scene"]["sdfs"] = [
     {"pos": [0.0, 0.0, -1.9], "type": 7, "params": [0.0, 0.2425356, 0.9701425, 0.0], "material": {"color": [0.6, 0.6, 0.6], "type": 1}},   # SDF_PLANE
 ]
 
+# branch-coverage scenes (round 2, profiles/r02_oracle_coverage.txt): the rarely taken branches of the reference
+# tiny mesh = a BVH whose root is a leaf (bvh.cl:34-40,121-128) with skewed vertex normals (shading normal against the
+# geometric side: the wi.z <= 0 exits of the BSDFs), low bounce caps (pathtracing.cl:109-115), a large clear glass
+# sphere in front of the camera (total internal reflection, Fresnel.cl:47), a mirror, a nearly smooth rough dielectric
+SCENES["cornell_edge"] = cornell({"color": [0.9, 0.9, 0.8], "type": 4, "roughness": 0.05}, obj="tiny.obj",
+                                 extra_spheres=[{"pos": [0.3, 1.1, 1.4], "radius": 0.9, "material": {"color": WHITE, "type": 3}},
+                                                {"pos": [-1.3, 0.5, 0.2], "radius": 0.5, "material": {"color": [0.9, 0.9, 0.9], "type": 2}},
+                                                {"pos": [1.3, 0.45, -0.3], "radius": 0.45, "material": {"color": WHITE, "type": 11, "dist": 2, "roughness": 0.001}},
+                                                {"pos": [-0.6, 0.3, 1.5], "radius": 0.3, "material": {"color": [0.7, 0.8, 0.9], "type": 1}}],
+                                 st=settings(6, 3, 2, 3, 4))
+# an absorbing-only medium (media/homogeneous.cl:16-21) and a dense one that runs into MAX_SCATTERING_EVENTS (pathtracing.cl:38)
+# (the two-triangle mesh again: as clear glass it is hit from behind at grazing angles -> total internal reflection,
+#  Fresnel.cl:47 and the F == 1 exit of Dielectric.cl; as Lambert its skewed normals give wi.z <= 0, Lambert.cl:6,19)
+SCENES["cornell_absfog"] = cornell({"color": WHITE, "type": 3}, obj="tiny.obj", medium={"density": 0.5, "sigmaA": 0.6, "sigmaS": 0.0}, st=settings(12, 4, 16, 32, 8))
+SCENES["cornell_fogcap"] = cornell({"color": WHITE, "type": 1}, obj="tiny.obj",
+                                   light={"pos": [0.0, 1.5, -1.0], "radius": 0.2, "material": {"color": [34.0, 34.0, 34.0], "type": 0}},
+                                   medium={"density": 1.5, "sigmaA": 0.05, "sigmaS": 1.0}, st=settings(24, 6, 16, 32, 2))
+
 if __name__ == "__main__":
     for name, doc in SCENES.items():
         with open(os.path.join(HERE, name + ".json"), "w") as f:

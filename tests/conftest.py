@@ -49,5 +49,18 @@ VARIANTS = {
     "cornell_mixed": ("cornell_mixed.json", 0, True),           # Phong rough conductor, mirror, absorbing (rough) dielectrics
     "cornell_quadlight": ("cornell_quadlight.json", 0, False),  # quad area light, coat over GGX, -alpha
     "cornell_sdf": ("cornell_sdf.json", 0, True),               # raymarched SDF sphere / box / round box / plane
+    # branch-coverage variants (profiles/r02_oracle_coverage.txt)
+    "cornell_edge": ("cornell_edge.json", 0, True),             # leaf-root BVH, pinhole camera, low bounce caps, TIR, mirror, skewed normals
+    "cornell_absfog": ("cornell_absfog.json", 0, False),        # absorption-only medium
+    "cornell_fogcap": ("cornell_fogcap.json", 1, True),         # dense HG medium running into MAX_SCATTERING_EVENTS
 }
+PINHOLE_VARIANTS = {"cornell_edge"}                             # apertureRadius 0: camera.cl:44-56 takes the pinhole branch
 ALPHA_VARIANTS = {"cornell_quadlight"}                          # built / run with ALPHA_TESTING (the reference's -alpha flag)
+
+
+def variant_camera(prt, variant, W, H):
+    """the reference's default camera (src/main.cpp:312-319) for a variant; PINHOLE_VARIANTS close the aperture"""
+    cam = prt.default_camera(W, H)
+    if variant in PINHOLE_VARIANTS:
+        cam.apertureRadius = 0.0
+    return cam

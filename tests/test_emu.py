@@ -10,7 +10,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ALPHA_VARIANTS, GOLDEN, ROOT, VARIANTS
+from conftest import ALPHA_VARIANTS, GOLDEN, ROOT, VARIANTS, variant_camera
 
 sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
 
@@ -27,7 +27,7 @@ def _scene(prt, variant, W, H):
     scene = prt.HostScene(scene_json)
     cfg = scene.config(alpha_testing=variant in ALPHA_VARIANTS)
     cfg.phase_function = phase
-    return scene, cfg, prt.default_camera(W, H), (prt.make_sky(64, 32) if use_env else None)
+    return scene, cfg, variant_camera(prt, variant, W, H), (prt.make_sky(64, 32) if use_env else None)
 
 
 def _same(oracle, s0, i0, s1, i1, what):

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import ALPHA_VARIANTS, GOLDEN, PKG_NAME, VARIANTS
+from conftest import ALPHA_VARIANTS, GOLDEN, PKG_NAME, VARIANTS, variant_camera
 
 pytestmark = pytest.mark.gpu
 
@@ -17,7 +17,7 @@ def _setup(prt, variant, W, H, rows=None, row0=0):
     scene = prt.HostScene(scene_json)
     cfg = scene.config(alpha_testing=variant in ALPHA_VARIANTS)
     cfg.phase_function = phase
-    cam = prt.default_camera(W, H)
+    cam = variant_camera(prt, variant, W, H)
     env = prt.make_sky(64, 32) if use_env else None
     r = prt.Renderer(cfg, device=0)
     r.upload_scene(scene)

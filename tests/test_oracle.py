@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import ALPHA_VARIANTS, GOLDEN, VARIANTS
+from conftest import ALPHA_VARIANTS, GOLDEN, VARIANTS, variant_camera
 
 
 def setup(prt, variant, W, H):
@@ -14,7 +14,7 @@ def setup(prt, variant, W, H):
     scene = prt.HostScene(scene_json)
     cfg = scene.config(alpha_testing=variant in ALPHA_VARIANTS)
     cfg.phase_function = phase
-    return scene, cfg, prt.default_camera(W, H), (prt.make_sky(64, 32) if use_env else None)
+    return scene, cfg, variant_camera(prt, variant, W, H), (prt.make_sky(64, 32) if use_env else None)
 
 
 @pytest.mark.parametrize("variant", list(VARIANTS) + ["cornell_diffuse_spp"])
