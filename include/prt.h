@@ -185,6 +185,11 @@ int prt_query_counts(prt_ctx* ctx, uint32_t spp, prt_stats* stats);
  * 10 fma(a,b,a), 11 fmin(a,b), 12 fmax(a,b), 13 round, 14 floor, 15 1/a, 16 cbrt).  Host arrays in and out.
  * The numerics contract says the result must equal the host evaluation bit for bit. */
 int prt_selftest_math(prt_ctx* ctx, int fn, const float* a, const float* b, float* out, int n);
+/* test hook: one device FUNCTION of the radiance loop on `n` cases (BSDF sampling / evaluation, microfacet terms,
+ * Fresnel, light sampling, medium and phase sampling, camera ray, primitive tests, environment lookup -- fn 1..11, layouts in
+ * csrc/hip/pt_selftest.h): 80 floats of shared parameters, 32 floats in and 32 floats out per case.  The known-answer
+ * fixtures tests/golden/kat_*.npz hold what the REFERENCE's own functions return on the same cases. */
+int prt_selftest_fn(prt_ctx* ctx, int fn, const float* params, const float* in, float* out, int n);
 
 const char* prt_last_error(prt_ctx* ctx);
 /* message for a failed prt_create (ctx == NULL) */

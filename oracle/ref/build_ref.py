@@ -96,17 +96,19 @@ def build_support(tmp):
     return objs
 
 
-def build_variant(name, scene, width, height, alpha, shadow_stack, phase, blob_dir, exe, tmp, support):
+def build_variant(name, scene, width, height, alpha, shadow_stack, phase, blob_dir, exe, tmp, support, kat=False):
     cl = os.path.join(tmp, name + ".cl")
     blob = os.path.join(blob_dir, name + ".sceneblob")
     run([exe, os.path.abspath(scene), str(width), str(height), "1" if alpha else "0", cl, blob],
         cwd=os.path.join(tmp, "run"))
-    if shadow_stack:
+    if shadow_stack or kat:
         text = open(cl).read()
         if shadow_stack:
             needle = "#define STACK_SIZE 8\n"
             assert text.count(needle) == 1, "shadow stack define not found exactly once"
             text = text.replace(needle, "#define STACK_SIZE %d\n" % shadow_stack)
+        if kat:     # the per-function harness (own code) joins the reference's translation unit, in the temp text only
+            text += "\n" + open(os.path.join(HERE, "kat_harness.cl")).read()
         open(cl, "w").write(text)
     obj = os.path.join(tmp, name + ".o")
     run([CLANG, "-x", "cl", "-cl-std=CL1.2", "-Xclang", "-finclude-default-header",
@@ -128,6 +130,7 @@ def main():
     ap.add_argument("--shadow-stack", type=int, default=64)
     ap.add_argument("--phase", default="", choices=["", "isotropic", "hg", "rayleigh"], help="phase function of the global medium")
     ap.add_argument("--blob-dir", default=os.path.join(ROOT, "tests", "golden"))
+    ap.add_argument("--kat", action="store_true", help="append oracle/ref/kat_harness.cl (per-function known-answer entry point kat_run)")
     a = ap.parse_args()
     if not os.path.isdir(REF):
         print("reference not present: nothing to build (the GPU box uses the prebuilt files)")
@@ -141,7 +144,7 @@ def main():
         for v in a.variant:
             name, scene = v.split("=", 1)
             so = build_variant(name, scene, a.width, a.height, a.alpha, a.shadow_stack, a.phase,
-                               a.blob_dir, exe, tmp, support)
+                               a.blob_dir, exe, tmp, support, kat=a.kat)
             print("built", so)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

@@ -249,6 +249,16 @@ class Renderer:
                                              out.ctypes.data_as(C.c_void_p), a.size), "prt_selftest_math")
         return out
 
+    def selftest_fn(self, fn, params, cases):
+        """prt_selftest_fn: params = 80 floats, cases = [n, 32] float32 -> [n, 32] float32"""
+        params = np.ascontiguousarray(params, dtype=np.float32)
+        cases = np.ascontiguousarray(cases, dtype=np.float32)
+        assert params.size == 80 and cases.ndim == 2 and cases.shape[1] == 32
+        out = np.zeros_like(cases)
+        self._chk(self.lib.prt_selftest_fn(self.ctx, int(fn), params.ctypes.data_as(C.c_void_p), cases.ctypes.data_as(C.c_void_p),
+                                           out.ctypes.data_as(C.c_void_p), cases.shape[0]), "prt_selftest_fn")
+        return out
+
     def close(self):
         if getattr(self, "ctx", None) and self.ctx.value:
             self.lib.prt_destroy(self.ctx)

@@ -93,6 +93,7 @@ PRT_API = [
     ("prt_get_stats", C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     ("prt_query_counts", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(Stats)]),
     ("prt_selftest_math", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    ("prt_selftest_fn", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     ("prt_last_error", C.c_char_p, [C.c_void_p]),
     ("prt_last_global_error", C.c_char_p, []),
 ]

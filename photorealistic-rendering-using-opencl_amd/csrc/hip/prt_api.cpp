@@ -609,3 +609,23 @@ extern "C" int prt_selftest_math(prt_ctx* c, int fn, const float* a, const float
     HIPCHK(c, e);
     return PRT_OK;
 }
+
+extern "C" int prt_selftest_fn(prt_ctx* c, int fn, const float* params, const float* in, float* out, int n) {
+    CTX_CHECK(c);
+    if (!params || !in || !out || n <= 0 || fn < 1 || fn > 11) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_selftest_fn: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    float *dp = nullptr, *di = nullptr, *dout = nullptr;
+    const size_t bytes = (size_t)n * 32 * sizeof(float);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&dp), 80 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&di), bytes);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&dout), bytes);
+    if (e == hipSuccess) e = hipMemcpy(dp, params, 80 * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(di, in, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) { launch_selftest_fn(fn, dp, di, dout, n, c->stream); e = hipStreamSynchronize(c->stream); }
+    if (e == hipSuccess) e = hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost);
+    if (dp) (void)hipFree(dp);
+    if (di) (void)hipFree(di);
+    if (dout) (void)hipFree(dout);
+    HIPCHK(c, e);
+    return PRT_OK;
+}

@@ -15,6 +15,7 @@
 
 #include "pt_device.h"
 #include "pt_launch.h"
+#include "pt_selftest.h"
 
 namespace prt {
 
@@ -276,6 +277,17 @@ __global__ void selftest_math_kernel(int fn, const float* __restrict__ a, const 
     out[i] = r;
 }
 
+// per-function known-answer entry (pt_selftest.h): one case per lane
+__global__ void selftest_fn_kernel(int fn, const float* __restrict__ params, const float* __restrict__ in, float* __restrict__ out, int n) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    float p[80], x[32], y[32];
+    for (int k = 0; k < 80; ++k) p[k] = params[k];
+    for (int k = 0; k < 32; ++k) x[k] = in[32 * (size_t)i + k];
+    selftest_fn(fn, p, x, y);
+    for (int k = 0; k < 32; ++k) out[32 * (size_t)i + k] = y[k];
+}
+
 // ---- host-side launchers -------------------------------------------------------------------------------
 template <unsigned MATS, bool MEDIUM, int WAVES>
 static void launch_variant_w(const DevScene& sc, const DevCamera& cam, const DevState& S, const FrameArgs& fa, float4* fb,
@@ -349,6 +361,9 @@ void launch_rtd_to_state(const prt_path_state* in, const DevState& S, float4* fb
 }
 void launch_selftest_math(int fn, const float* a, const float* b, float* out, int n, hipStream_t stream) {
     hipLaunchKernelGGL(selftest_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, fn, a, b, out, n);
+}
+void launch_selftest_fn(int fn, const float* params, const float* in, float* out, int n, hipStream_t stream) {
+    hipLaunchKernelGGL(selftest_fn_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, fn, params, in, out, n);
 }
 void launch_tonemap(const float4* fb, unsigned char* out, const FrameArgs& fa, hipStream_t stream) {
     const size_t npix = (size_t)fa.width * (size_t)fa.rows;

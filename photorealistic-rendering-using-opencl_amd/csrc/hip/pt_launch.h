@@ -18,6 +18,7 @@ void make_dev_camera(const prt_camera& in, DevCamera& out);
 void launch_state_to_rtd(const DevState& S, prt_path_state* out, size_t n, hipStream_t stream);
 void launch_rtd_to_state(const prt_path_state* in, const DevState& S, float4* fb, size_t n, hipStream_t stream);
 void launch_selftest_math(int fn, const float* a, const float* b, float* out, int n, hipStream_t stream);
+void launch_selftest_fn(int fn, const float* params, const float* in, float* out, int n, hipStream_t stream);
 void launch_tonemap(const float4* fb, unsigned char* out, const FrameArgs& fa, hipStream_t stream);
 void launch_count(const DevState& S, size_t n, unsigned spp, unsigned long long* out3, hipStream_t stream);
 

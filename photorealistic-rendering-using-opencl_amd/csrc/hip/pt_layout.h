@@ -45,6 +45,24 @@ struct alignas(16) DevQuad {
     float normal[3]; float u0;     // u0 = e0e0 * 2^-24, u1 = e1e1 * 2^-24: half an ulp of 1.0 in units of the divisor, or a
     float anchor[3]; float u1;     // NaN when the divisor is outside [2^-40, 2^40] (out_of_unit_range then divides)
 };
+// Mesh.joker {base, edge0, edge1, normal, area} (include/Scene/scene.h:434-452) -> DevQuad, with the ray-independent
+// values of kernels/geometry/quad.cl:16,26-27 (anchor = base - (edge0 + edge1) * 0.5f, dot(edge, edge)) computed once
+// by the reference's own float operations, and u = half an ulp of 1.0 in units of the divisor for out_of_unit_range
+#if defined(__HIPCC__)
+#define PT_LAYOUT_HD __host__ __device__ inline
+#else
+#define PT_LAYOUT_HD inline
+#endif
+PT_LAYOUT_HD float quad_half_ulp(float c) { return (c >= 9.094947017729282e-13f && c <= 1099511627776.0f) ? c * 5.9604644775390625e-08f : __builtin_nanf(""); }
+PT_LAYOUT_HD void pack_quad(const float* j, DevQuad& d) {
+    for (int k = 0; k < 3; ++k) { d.base[k] = j[k]; d.edge0[k] = j[3 + k]; d.edge1[k] = j[6 + k]; d.normal[k] = j[9 + k]; }
+    d.area = j[12];
+    for (int k = 0; k < 3; ++k) d.anchor[k] = d.base[k] - (d.edge0[k] + d.edge1[k]) * 0.5f;
+    d.e0e0 = d.edge0[0] * d.edge0[0] + d.edge0[1] * d.edge0[1] + d.edge0[2] * d.edge0[2];
+    d.e1e1 = d.edge1[0] * d.edge1[0] + d.edge1[1] * d.edge1[1] + d.edge1[2] * d.edge1[2];
+    d.u0 = quad_half_ulp(d.e0e0); d.u1 = quad_half_ulp(d.e1e1);
+}
+
 struct alignas(16) DevSdf { float pos[3]; uint32_t type; float params[4]; };     // Mesh.pos, Mesh.t, joker.s0123
 struct alignas(16) DevMaterial {
     float color[3]; float roughness;

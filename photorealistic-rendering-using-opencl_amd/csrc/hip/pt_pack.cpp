@@ -56,15 +56,7 @@ int pack_scene(const prt_config& cfg, const prt_scene_desc* s, PackedScene& out,
             if (!(m.t & PRT_GEOM_QUAD)) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: mesh order/type mismatch (quad expected)");
             DevQuad& d = quads[i - n_sph - n_sdf];
             std::memset(&d, 0, sizeof(d));
-            for (int k = 0; k < 3; ++k) { d.base[k] = m.joker[k]; d.edge0[k] = m.joker[3 + k]; d.edge1[k] = m.joker[6 + k]; d.normal[k] = m.joker[9 + k]; }
-            d.area = m.joker[12];
-            // kernels/geometry/quad.cl:16 anchor = base - (edge0 + edge1) * 0.5f ; :26-27 dot(edge, edge)
-            for (int k = 0; k < 3; ++k) d.anchor[k] = d.base[k] - (d.edge0[k] + d.edge1[k]) * 0.5f;
-            d.e0e0 = d.edge0[0] * d.edge0[0] + d.edge0[1] * d.edge0[1] + d.edge0[2] * d.edge0[2];
-            d.e1e1 = d.edge1[0] * d.edge1[0] + d.edge1[1] * d.edge1[1] + d.edge1[2] * d.edge1[2];
-            // pt_device.h out_of_unit_range: half an ulp of 1.0 scaled by the divisor, NaN = "divide instead"
-            auto half_ulp = [](float c) { return (c >= 9.094947017729282e-13f && c <= 1099511627776.0f) ? c * 5.9604644775390625e-08f : std::nanf(""); };
-            d.u0 = half_ulp(d.e0e0); d.u1 = half_ulp(d.e1e1);
+            pack_quad(m.joker, d);
         }
     }
     if (s->obj_material) mats[n_mesh + 1] = pack_material(*s->obj_material);

@@ -103,6 +103,16 @@ SCENES["cornell_fogcap"] = cornell({"color": WHITE, "type": 1}, obj="tiny.obj",
                                    light={"pos": [0.0, 1.5, -1.0], "radius": 0.2, "material": {"color": [34.0, 34.0, 34.0], "type": 0}},
                                    medium={"density": 1.5, "sigmaA": 0.05, "sigmaS": 1.0}, st=settings(24, 6, 16, 32, 2))
 
+# every material type + a global medium compiled in at once: the reference build the per-function known-answer vectors
+# come from (tests/golden/make_kat.py; the harness passes its own Material / Mesh / medium records at run time)
+SCENES["kat_all"] = cornell({"color": WHITE, "type": 4, "roughness": 0.1},
+                            extra_spheres=[{"pos": [-1.2, 0.4, 0.5], "radius": 0.4, "material": {"color": WHITE, "type": 1}},
+                                           {"pos": [-0.4, 0.4, 1.2], "radius": 0.4, "material": {"color": WHITE, "type": 2}},
+                                           {"pos": [0.4, 0.4, 1.2], "radius": 0.4, "material": {"color": WHITE, "type": 3}},
+                                           {"pos": [1.2, 0.4, 0.5], "radius": 0.4, "material": {"color": WHITE, "type": 10, "dist": 2, "roughness": 0.2}},
+                                           {"pos": [1.2, 1.3, 0.5], "radius": 0.4, "material": {"color": WHITE, "type": 11, "dist": 1, "roughness": 0.2}}],
+                            medium={"density": 0.07, "sigmaA": 0.1, "sigmaS": 1.0})
+
 if __name__ == "__main__":
     for name, doc in SCENES.items():
         with open(os.path.join(HERE, name + ".json"), "w") as f:

@@ -15,7 +15,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 def build():
     srcs = [os.path.join(HERE, "pt_emu.cpp"), os.path.join(PKG, "csrc", "hip", "pt_pack.cpp")]
-    deps = srcs + [os.path.join(PKG, "csrc", "hip", f) for f in ("pt_device.h", "pt_layout.h", "pt_pack.h")] + \
+    deps = srcs + [os.path.join(PKG, "csrc", "hip", f) for f in ("pt_device.h", "pt_layout.h", "pt_pack.h", "pt_selftest.h")] + \
         [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include"))]
     if os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
         return LIB
@@ -38,7 +38,17 @@ def lib():
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_uint32, C.c_uint32, C.c_uint32, C.c_char_p, C.c_int]
+        _lib.emu_selftest_fn.restype = None
+        _lib.emu_selftest_fn.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     return _lib
+
+
+def selftest_fn(fn, params, cases):
+    params = np.ascontiguousarray(params, dtype=np.float32)
+    cases = np.ascontiguousarray(cases, dtype=np.float32)
+    out = np.zeros_like(cases)
+    lib().emu_selftest_fn(int(fn), params.ctypes.data_as(C.c_void_p), cases.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), cases.shape[0])
+    return out
 
 
 def render(state_dtype, cfg, desc, camera, W, H, seed_pairs, first_frame=1, state=None, env=None, spp_limit=0,

@@ -17,6 +17,7 @@
 
 #include "pt_device.h"
 #include "pt_pack.h"
+#include "pt_selftest.h"
 
 using namespace prt;
 using namespace prt::dev;
@@ -179,4 +180,9 @@ extern "C" int emu_render(const prt_config* cfg, const prt_scene_desc* desc, con
             }
         }
     return 0;
+}
+
+// prt_selftest_fn on the host: the same dispatcher (csrc/hip/pt_selftest.h) compiled for x86-64
+extern "C" void emu_selftest_fn(int fn, const float* params, const float* in, float* out, int n) {
+    for (int i = 0; i < n; ++i) selftest_fn(fn, params, in + 32 * (size_t)i, out + 32 * (size_t)i);
 }

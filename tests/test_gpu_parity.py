@@ -551,6 +551,75 @@ def test_full_size_frame_against_oracle_strips_and_properties(prt, oracle):
         rt.close()
 
 
+@pytest.mark.parametrize("variant", ["cornell_roughcond", "cornell_roughdiel", "cornell_media_hg"])
+def test_full_size_configs_3_and_4_against_oracle_strips(prt, oracle, variant):
+    """BASELINE configs 3a / 3b / 4 at their real size: 1920x1080 with the 1024x512 environment map (the small-size tests
+    use a 64x32 one).  Three 4-row oracle strips (global pixel coordinates: top, middle, bottom of the frame) must match
+    the GPU's full-frame pixels bit for bit, the counters must add up, and two frame batches must compose."""
+    W, H, frames = 1920, 1080, 28
+    scene_json, phase, use_env = VARIANTS[variant]
+    scene = prt.HostScene(scene_json)
+    cfg = scene.config()
+    cfg.phase_function = phase
+    cam = prt.default_camera(W, H)
+    env = prt.make_sky(1024, 512)
+    r = prt.Renderer(cfg, device=0)
+    r.upload_scene(scene)
+    r.upload_envmap(env)
+    r.set_camera(cam)
+    r.resize(W, H)
+    seeds = prt.seed_pairs(frames)
+    r.render_frames(seeds[:2 * 11])
+    r.render_frames(seeds[2 * 11:], first_frame=12)
+    img = r.read_framebuffer()
+    state = r.read_state().reshape(H, W)
+    st = r.counts()
+    assert st.segments == frames * W * H
+    assert st.samples == int(state["samples"].sum()) and int(state["acc"][..., 3].sum()) == st.segments
+    r.close()
+    rs = oracle.Restatement()
+    for row0 in (0, 538, 1076):
+        ostate, oimg = rs.render(cfg, scene.desc, cam, W, H, seeds, env=env, row0=row0, rows=4, threads=16)
+        _assert_same(oracle, ostate, oimg, state[row0:row0 + 4].reshape(-1), img[row0:row0 + 4], "%s full-size strip at row %d" % (variant, row0))
+
+
+def test_full_size_config_5_against_oracle_strips(prt, oracle):
+    """BASELINE config 5 at its real frame size: the 871 k-triangle stand-in at 3840x2160 (8.3 M pixels: tile indices past
+    2^17, pixel indices past 2^23), a few dozen frames.  Oracle strips at the top, through the mesh and at the bottom;
+    one of the eight row-block parts of the multi-GPU split against the same frame."""
+    prt.ensure_dragon_standin()
+    W, H, frames = 3840, 2160, 24
+    scene = prt.HostScene("cornell_dragon.json")
+    cfg = scene.config()
+    cam = prt.default_camera(W, H)
+    r = prt.Renderer(cfg, device=0)
+    r.upload_scene(scene)
+    r.set_camera(cam)
+    r.resize(W, H)
+    seeds = prt.seed_pairs(frames)
+    r.render_frames(seeds)
+    img = r.read_framebuffer()
+    state = r.read_state().reshape(H, W)
+    st = r.counts()
+    assert st.segments == frames * W * H
+    assert st.samples == int(state["samples"].sum()) and int(state["acc"][..., 3].sum()) == st.segments
+    r.close()
+    rs = oracle.Restatement()
+    for row0 in (0, 1300, 2156):
+        ostate, oimg = rs.render(cfg, scene.desc, cam, W, H, seeds, row0=row0, rows=4, threads=16)
+        _assert_same(oracle, ostate, oimg, state[row0:row0 + 4].reshape(-1), img[row0:row0 + 4], "dragon 4K strip at row %d" % row0)
+    part = 3
+    rows = np.array([y for y in range(H) if (y // 16) % 8 == part])
+    rt = prt.Renderer(cfg, device=0)
+    rt.upload_scene(scene)
+    rt.set_camera(cam)
+    rt.set_row_blocks(W, H, 16, 8, part)
+    rt.render_frames(seeds)
+    _assert_same(oracle, state[rows].reshape(-1).view(oracle.PATH_STATE_DTYPE), img[rows], rt.read_state(), rt.read_framebuffer(),
+                 "dragon 4K row blocks, part %d of 8" % part)
+    rt.close()
+
+
 def test_full_size_spp_render_is_complete(prt, oracle):
     """1920x1080 at 8 spp to completion: every pixel froze at exactly 8 paths, alpha = segments / samples"""
     W, H, spp = 1920, 1080, 8
@@ -624,3 +693,18 @@ def test_tonemap_matches_the_reference_shader_and_cli_writes_png(prt, oracle, tm
     assert (pix[:, 0] == 0).all()
     png = pix[:, 1:].reshape(H, W, 4)
     assert np.array_equal(png[::-1], ldr)             # the PNG is top-down, the framebuffer bottom-up; same render (deterministic)
+
+
+def test_device_functions_match_reference_kat(prt):
+    """prt_selftest_fn on the GPU against the per-function known-answer vectors of the reference build (tests/test_kat.py)"""
+    from test_kat import assert_kat_equal, kat_tables
+    scene = prt.HostScene("cornell_diffuse.json")
+    r = prt.Renderer(scene.config(), device=0)
+    n = 0
+    for name, fn, params, cases, expect, cols in kat_tables():
+        assert_kat_equal(name, r.selftest_fn(fn, params, cases), expect, cols)
+        n += 1
+    assert n >= 40
+    from test_kat import check_env_lookup
+    check_env_lookup(r.selftest_fn)             # read_imagef semantics worked out from the OpenCL 1.2 specification
+    r.close()
