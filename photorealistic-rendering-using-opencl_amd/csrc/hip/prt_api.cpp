@@ -52,9 +52,12 @@ struct prt_ctx {
     hipEvent_t sub_ev0[MAX_SUB][2] = {};          // its start (prt_render_spp times every launch)
     hipEvent_t fork_ev = nullptr;
     unsigned long long* h_unfinished = nullptr;   // pinned, [MAX_SUB][2]: written by the last wave of a launch
-    unsigned frames_per_launch = 128;              // frames a launch of render_kernel covers (PRT_FRAMES_PER_LAUNCH); measured on
-                                                   // MI355X: 32 -> 3.82, 64 -> 3.95, 128 -> 4.01 G segments/s, 256 the same
-    uint32_t walk_min_lanes = 4;                   // FrameArgs::walk_min_lanes (prt_set_walk_min_lanes, PRT_WALK_MIN_LANES)
+    // frames a launch of render_kernel covers (PRT_FRAMES_PER_LAUNCH).  Lanes drift apart in frame number inside a launch
+    // and the wave waits for its last lane at the end of each: long launches amortise that (cornell 1080p, MI355X:
+    // 128 -> 7.85, 256 -> 8.18, 512 -> 8.33, 1024 -> 8.38, 2048 -> 8.08 G segments/s; 2 x 100 ms launches in flight at 512)
+    unsigned frames_per_launch = 512;
+    // walk phases end below this many walking lanes (prt_set_walk_min_lanes): 1 -> 7.78, 4 -> 8.33, 6 -> 8.37, 8 -> 8.28, 12 -> 7.98
+    uint32_t walk_min_lanes = 6;                   // FrameArgs::walk_min_lanes (prt_set_walk_min_lanes, PRT_WALK_MIN_LANES)
     prt_stats stats{};
     std::string err;
     const char* variant = "";
