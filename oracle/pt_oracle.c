@@ -6,7 +6,7 @@
  * the product never links or calls anything in oracle/.
  *
  * Pinned by: oracle/_ref (the reference's own kernel text compiled for the host in the
- * development container) -- tests/test_oracle_vs_ref.py demands bit-identical path state and
+ * development container) -- tests/test_oracle.py demands bit-identical path state and
  * framebuffer on every scene variant -- and by the golden fixtures under tests/golden/ produced
  * by that reference build.
  *
