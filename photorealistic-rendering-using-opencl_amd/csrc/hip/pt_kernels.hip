@@ -29,9 +29,10 @@ using namespace dev;
 
 // One wave = one 8x8 tile; every lane runs the lane machine of pt_device.h on its pixel until it has done its n_frames
 // segments (or froze).  What is wave-level here is only the SCHEDULE: when the two walk phases of an iteration end.
-//   walk phase rule: go on while at least fa.walk_min_lanes lanes are still walking; below that, stop as soon as the
-//   iteration has something else to do (a lane finished its walk in this phase, or lanes are waiting in a later stage).
-//   A lane cut off keeps its WalkState and LDS stack and resumes in the same phase of the next iteration.
+//   walk phase rule: go on while at least fa.walk_min_lanes (closest-hit phase) / fa.shadow_min_lanes (any-hit phase) lanes
+//   are still walking; below that, stop as soon as the iteration has something else to do (a lane finished its walk in
+//   this phase, or lanes are waiting in a later stage).  A lane cut off keeps its WalkState and LDS stack and resumes in
+//   the same phase of the next iteration.
 // WAVES = waves per SIMD the register allocator leaves room for.
 template <unsigned MATS, bool MEDIUM, int WAVES>
 __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene sc, const DevCamera cam, const DevState S,
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene 
     extern __shared__ unsigned lds_stack[];                     // sc.stack_levels x PT_BLOCK, sized by the launch
     TravStack stk;
     stk.lds = lds_stack + threadIdx.x; stk.stride = PT_BLOCK;
-    const unsigned T = fa.walk_min_lanes;
+    const unsigned T = fa.walk_min_lanes, TD = fa.shadow_min_lanes;
     for (;;) {
         const bool runnable = lane_runnable(fa, L);
         if (!__any(runnable || L.stage != ST_READY)) break;     // every lane has done its frames (or is frozen)
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene 
                     walk_step(sc, true, wr, p, L.w, stk);
                     if (L.w.done) break;
                     const unsigned n_act = (unsigned)__popcll(__ballot(1));
-                    if (n_act < T && (n_act < n_start || other_work)) break;
+                    if (n_act < TD && (n_act < n_start || other_work)) break;
                 }
             }
             if (walking && L.w.done) { L.occluded = L.w.found; L.stage = ST_FINISH; }

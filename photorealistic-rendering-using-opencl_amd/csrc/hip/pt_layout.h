@@ -129,7 +129,8 @@ struct FrameArgs {
                                             // done}; the last wave of the launch writes the count here (pinned host memory) and
                                             // zeroes the pair for the next launch: no copy / fill kernels between launches
     uint32_t tile_first, tile_stride;       // this launch covers the tiles tile_first + k * tile_stride (sub-part of the frame)
-    uint32_t walk_min_lanes;                // lane machine: a walk phase of a wave ends once fewer lanes than this are still walking
+    uint32_t walk_min_lanes;                // lane machine: a closest-hit walk phase of a wave ends once fewer lanes than this are still walking
+    uint32_t shadow_min_lanes;              // ... and an any-hit (shadow ray) phase below this many
 };
 
 }  // namespace prt
