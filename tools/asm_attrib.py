@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """development helper: attributes the vector-ALU instructions of one kernel in a `hipcc -S -g` listing to source
 functions (by .loc file:line -> enclosing function found with a crude scan of the source).
-usage: asm_attrib.py listing.s <kernel symbol substring> [valu|salu|all]"""
+usage: asm_attrib.py listing.s <kernel symbol substring> [valu|salu|all] [first last]   (listing lines as asm_loops.py prints them)"""
 import collections
 import os
 import re
@@ -19,12 +19,13 @@ start = next(i for i, l in enumerate(txt) if l.startswith("_ZN") and sys.argv[2]
 end = next(i for i in range(start + 1, len(txt)) if ".Lfunc_end" in txt[i])
 cur = None
 hist = collections.Counter()
-for l in txt[start:end]:
+lo, hi = (int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (start, end)
+for n, l in enumerate(txt[start:end], start):
     m = re.match(r"\s*\.loc\s+(\d+)\s+(\d+)", l)
     if m:
         cur = (int(m.group(1)), int(m.group(2)))
         continue
-    if re.match(pat, l) and cur:
+    if re.match(pat, l) and cur and lo <= n <= hi:
         hist[cur] += 1
 # enclosing function per source line
 func_of = {}
