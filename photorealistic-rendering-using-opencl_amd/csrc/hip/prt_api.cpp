@@ -140,6 +140,9 @@ static void free_scene(prt_ctx* c) {
 }
 
 extern "C" void prt_destroy(prt_ctx* c) {
+#ifdef PT_PHASE_CLOCKS
+    if (c) { (void)hipDeviceSynchronize(); prt::dump_phase_clocks(); }
+#endif
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);

@@ -10,6 +10,7 @@
 // tiles on two streams (prt_api.cpp).
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -34,6 +35,13 @@ using namespace dev;
 //   this phase, or lanes are waiting in a later stage).  A lane cut off keeps its WalkState and LDS stack and resumes in
 //   the same phase of the next iteration.
 // WAVES = waves per SIMD the register allocator leaves room for.
+#ifdef PT_PHASE_CLOCKS                    // development builds: cycles of a wave per phase of the iteration (tools/phase_clocks.sh)
+__device__ unsigned long long g_phase_clocks[8];
+#define PT_CLK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); clk_[k] += now_ - last_; last_ = now_; } while (0)
+#else
+#define PT_CLK(k) do { } while (0)
+#endif
+
 template <unsigned MATS, bool MEDIUM, int WAVES>
 __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene sc, const DevCamera cam, const DevState S,
                                                                  const FrameArgs fa, float4* __restrict__ fb) {
@@ -66,10 +74,15 @@ __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene 
     TravStack stk;
     stk.lds = lds_stack + threadIdx.x; stk.stride = PT_BLOCK;
     const unsigned T = fa.walk_min_lanes, TD = fa.shadow_min_lanes;
+#ifdef PT_PHASE_CLOCKS
+    unsigned long long clk_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_readcyclecounter();
+#endif
     for (;;) {
         const bool runnable = lane_runnable(fa, L);
         if (!__any(runnable || L.stage != ST_READY)) break;     // every lane has done its frames (or is frozen)
+        PT_CLK(7);
         if (runnable) lane_front<MATS, MEDIUM>(sc, cam, fa, L, gx, gy);                                  // A
+        PT_CLK(0);
         {                                                                                                 // B
             const bool walking = L.stage == ST_WALKC;
             const Ray wr = lane_closest_ray<MEDIUM>(L);
@@ -86,9 +99,12 @@ __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene 
                     if (n_act < T && (n_act < n_start || other_work)) break;
                 }
             }
+            PT_CLK(1);
             if (walking && L.w.done) lane_closest_done<MATS, MEDIUM>(sc, L);
+            PT_CLK(2);
         }
         if (L.stage == ST_BACK) lane_back<MATS, MEDIUM>(sc, L);                                          // C
+        PT_CLK(3);
         {                                                                                                 // D
             const bool walking = L.stage == ST_WALKS;
             const Ray wr = lane_shadow_ray<MEDIUM>(L);
@@ -107,8 +123,16 @@ __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene 
             }
             if (walking && L.w.done) { L.occluded = L.w.found; L.stage = ST_FINISH; }
         }
+        PT_CLK(4);
         if (L.stage == ST_FINISH) lane_finish<MEDIUM>(sc, L);                                            // E
+        PT_CLK(5);
+#ifdef PT_PHASE_CLOCKS
+        ++clk_[6];
+#endif
     }
+#ifdef PT_PHASE_CLOCKS
+    if (lane == (int)__builtin_ctzll(__ballot(1))) for (int k = 0; k < 8; ++k) atomicAdd(&g_phase_clocks[k], clk_[k]);
+#endif
     if (L.f) {
         S.q0[id] = make_float4(L.origin.x, L.origin.y, L.origin.z, L.t);
         S.q1[id] = make_float4(L.dir.x, L.dir.y, L.dir.z, L.time);
@@ -320,6 +344,19 @@ static void launch_variant(const DevScene& sc, const DevCamera& cam, const DevSt
 
 // Variant choice = the AOT analogue of the reference's per-scene program build (include/CL/cl_kernel.h):
 // material set (LIGHT|DIFF only, or generic) x global medium.
+#ifdef PT_PHASE_CLOCKS
+void dump_phase_clocks() {
+    unsigned long long h[8] = {0};
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase_clocks), sizeof(h)) != hipSuccess) return;
+    const char* names[8] = {"A front", "B walk", "B closest_done", "C back", "D shadow walk", "E finish", "iterations", "loop head"};
+    double tot = 0;
+    for (int k = 0; k < 8; ++k) if (k != 6) tot += (double)h[k];
+    for (int k = 0; k < 8; ++k)
+        if (k == 6) fprintf(stderr, "phase clocks: %-16s %llu (%.0f cycles each)\n", names[k], h[k], h[k] ? tot / (double)h[k] : 0.0);
+        else fprintf(stderr, "phase clocks: %-16s %5.1f %%\n", names[k], 100.0 * (double)h[k] / tot);
+}
+#endif
+
 const char* launch_render(const DevScene& sc, const DevCamera& cam, const DevState& S, const FrameArgs& fa, float4* fb,
                           hipStream_t stream) {
     constexpr unsigned LD = PRT_MAT_LIGHT | PRT_MAT_DIFF;

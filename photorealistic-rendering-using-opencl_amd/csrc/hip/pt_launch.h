@@ -13,6 +13,9 @@ const char* launch_render(const DevScene& sc, const DevCamera& cam, const DevSta
                           hipStream_t stream);
 // workgroups (tiles) launch_render uses for a width x rows frame part
 unsigned render_tile_count(int width, int rows);
+#ifdef PT_PHASE_CLOCKS
+void dump_phase_clocks();                 // development builds: prints the per-phase cycle shares of all launches so far
+#endif
 // per-camera part of createCamRay (camera.cl:19-28), on the host with the arithmetic of pt_device.h
 void make_dev_camera(const prt_camera& in, DevCamera& out);
 void launch_state_to_rtd(const DevState& S, prt_path_state* out, size_t n, hipStream_t stream);

@@ -34,7 +34,7 @@ void run_tile(const DevScene& sc, const DevCamera& cam, const FrameArgs& fa, int
               uint32_t sched_seed, std::vector<unsigned>& stack_mem) {
     Lane L[64];
     bool in_frame[64];
-    int gxs[64], gys[64];
+    int gxs[64] = {0}, gys[64] = {0};
     size_t ids[64];
     for (int lane = 0; lane < 64; ++lane) {
         const int lx = tile_x * 8 + (lane & 7), ly = tile_y * 8 + (lane >> 3);
