@@ -22,6 +22,9 @@ namespace prt {
 
 using namespace dev;
 
+#ifndef PT_BIG_WAVES
+#define PT_BIG_WAVES 5      // the same for trees beyond one XCD's L2 and for SDF scenes (96 VGPRs)
+#endif
 #ifndef PT_MIN_WAVES
 #define PT_MIN_WAVES 4      // waves per SIMD the register allocator must leave room for (128 VGPRs)
 #endif
@@ -336,7 +339,7 @@ static void launch_variant(const DevScene& sc, const DevCamera& cam, const DevSt
     // 5 waves where latency rules: the node records alone exceed one XCD's L2, or the scene raymarches SDFs (+11 %)
     const bool big = forced ? forced >= 5 : (sc.n_pairs > 65536u || sc.n_sdfs != 0u);
 #ifndef PT_DEV_ONE_VARIANT
-    if (big) launch_variant_w<MATS, MEDIUM, 5>(sc, cam, S, fa, fb, stream);
+    if (big) launch_variant_w<MATS, MEDIUM, PT_BIG_WAVES>(sc, cam, S, fa, fb, stream);
     else
 #endif
     launch_variant_w<MATS, MEDIUM, PT_MIN_WAVES>(sc, cam, S, fa, fb, stream);
