@@ -22,6 +22,10 @@ namespace prt {
 
 using namespace dev;
 
+#ifndef PT_WAIT_RATIO
+#define PT_WAIT_RATIO 1u    // a walk phase is cut short only while more than this many lanes wait per lane still walking (0: while
+                            // any lane waits -- the first form of the rule: 1.3 % slower on cornell, the same on the big mesh)
+#endif
 #ifndef PT_BIG_WAVES
 #define PT_BIG_WAVES 5      // the same for trees beyond one XCD's L2 and for SDF scenes (96 VGPRs)
 #endif
@@ -39,7 +43,7 @@ using namespace dev;
 //   the same phase of the next iteration.
 // WAVES = waves per SIMD the register allocator leaves room for.
 #ifdef PT_PHASE_CLOCKS                    // development builds: cycles of a wave per phase of the iteration (tools/phase_clocks.sh)
-__device__ unsigned long long g_phase_clocks[8];
+__device__ unsigned long long g_phase_clocks[12];    // 8: most iterations of one wave, 9: longest wave (cycles), 10: waves, 11: first start .. last end
 #define PT_CLK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); clk_[k] += now_ - last_; last_ = now_; } while (0)
 #else
 #define PT_CLK(k) do { } while (0)
@@ -79,6 +83,7 @@ __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene 
     const unsigned T = fa.walk_min_lanes, TD = fa.shadow_min_lanes;
 #ifdef PT_PHASE_CLOCKS
     unsigned long long clk_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_readcyclecounter();
+    const unsigned long long start_ = last_;
 #endif
     for (;;) {
         const bool runnable = lane_runnable(fa, L);
@@ -93,13 +98,13 @@ __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene 
             if (walking && L.fresh) { walk_begin(sc, false, wr, PT_INF, p, L.w, stk); L.fresh = false; }
             const bool go = walking && !L.w.done;
             const unsigned n_start = (unsigned)__popcll(__ballot(go));
-            const bool other_work = __any((walking && L.w.done) || L.stage == ST_BACK);
+            const unsigned n_other = (unsigned)__popcll(__ballot((walking && L.w.done) || L.stage == ST_BACK));
             if (go) {
                 for (;;) {
                     walk_step(sc, false, wr, p, L.w, stk);
                     if (L.w.done) break;
                     const unsigned n_act = (unsigned)__popcll(__ballot(1));
-                    if (n_act < T && (n_act < n_start || other_work)) break;
+                    if (n_act < T && n_other + (n_start - n_act) > PT_WAIT_RATIO * n_act) break;   // the lanes that wait outnumber the walkers
                 }
             }
             PT_CLK(1);
@@ -115,13 +120,13 @@ __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene 
             if (walking && L.fresh) { walk_begin(sc, true, wr, wr.t, p, L.w, stk); L.fresh = false; }
             const bool go = walking && !L.w.done;
             const unsigned n_start = (unsigned)__popcll(__ballot(go));
-            const bool other_work = __any((walking && L.w.done) || L.stage == ST_FINISH);
+            const unsigned n_other = (unsigned)__popcll(__ballot((walking && L.w.done) || L.stage == ST_FINISH));
             if (go) {
                 for (;;) {
                     walk_step(sc, true, wr, p, L.w, stk);
                     if (L.w.done) break;
                     const unsigned n_act = (unsigned)__popcll(__ballot(1));
-                    if (n_act < TD && (n_act < n_start || other_work)) break;
+                    if (n_act < TD && n_other + (n_start - n_act) > PT_WAIT_RATIO * n_act) break;
                 }
             }
             if (walking && L.w.done) { L.occluded = L.w.found; L.stage = ST_FINISH; }
@@ -134,7 +139,12 @@ __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene 
 #endif
     }
 #ifdef PT_PHASE_CLOCKS
-    if (lane == (int)__builtin_ctzll(__ballot(1))) for (int k = 0; k < 8; ++k) atomicAdd(&g_phase_clocks[k], clk_[k]);
+    if (lane == (int)__builtin_ctzll(__ballot(1))) {
+        for (int k = 0; k < 8; ++k) atomicAdd(&g_phase_clocks[k], clk_[k]);
+        atomicMax(&g_phase_clocks[8], clk_[6]);
+        atomicMax(&g_phase_clocks[9], last_ - start_);
+        atomicAdd(&g_phase_clocks[10], 1ull);
+    }
 #endif
     if (L.f) {
         S.q0[id] = make_float4(L.origin.x, L.origin.y, L.origin.z, L.t);
@@ -349,7 +359,7 @@ static void launch_variant(const DevScene& sc, const DevCamera& cam, const DevSt
 // material set (LIGHT|DIFF only, or generic) x global medium.
 #ifdef PT_PHASE_CLOCKS
 void dump_phase_clocks() {
-    unsigned long long h[8] = {0};
+    unsigned long long h[12] = {0};
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase_clocks), sizeof(h)) != hipSuccess) return;
     const char* names[8] = {"A front", "B walk", "B closest_done", "C back", "D shadow walk", "E finish", "iterations", "loop head"};
     double tot = 0;
@@ -357,6 +367,8 @@ void dump_phase_clocks() {
     for (int k = 0; k < 8; ++k)
         if (k == 6) fprintf(stderr, "phase clocks: %-16s %llu (%.0f cycles each)\n", names[k], h[k], h[k] ? tot / (double)h[k] : 0.0);
         else fprintf(stderr, "phase clocks: %-16s %5.1f %%\n", names[k], 100.0 * (double)h[k] / tot);
+    if (h[10]) fprintf(stderr, "phase clocks: waves %llu, iterations per wave mean %.0f max %llu, cycles per wave mean %.0f max %llu\n", h[10],
+                       (double)h[6] / (double)h[10], h[8], tot / (double)h[10], h[9]);
 }
 #endif
 

@@ -67,7 +67,7 @@ void run_tile(const DevScene& sc, const DevCamera& cam, const FrameArgs& fa, int
         RayPre p[64];
         bool go[64];
         unsigned n_start = 0;
-        bool other_work = false;
+        unsigned n_other = 0;
         for (int lane = 0; lane < 64; ++lane) {
             go[lane] = false;
             if (!in_frame[lane]) continue;
@@ -80,7 +80,7 @@ void run_tile(const DevScene& sc, const DevCamera& cam, const FrameArgs& fa, int
             }
             go[lane] = walking && !l.w.done;
             n_start += go[lane] ? 1u : 0u;
-            other_work |= (walking && l.w.done) || l.stage == waiting_stage;
+            n_other += ((walking && l.w.done) || l.stage == waiting_stage) ? 1u : 0u;
         }
         const unsigned T = phase_T();
         for (;;) {
@@ -93,7 +93,7 @@ void run_tile(const DevScene& sc, const DevCamera& cam, const FrameArgs& fa, int
                 if (L[lane].w.done) go[lane] = false; else ++n_act;
             }
             if (!stepped || n_act == 0) break;
-            if (n_act < T && (n_act < n_start || other_work)) break;
+            if (n_act < T && n_other + (n_start - n_act) > n_act) break;      // render_kernel's rule (PT_WAIT_RATIO 1)
         }
     };
 
