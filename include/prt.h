@@ -144,8 +144,12 @@ int prt_render_frames(prt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, con
 
 /* "N spp": frames 1,2,... with a pixel frozen once its N-th path has terminated
  * (reset && samples == spp).  Runs until every pixel is frozen or max_frames frames were used;
- * seed_pairs must hold max_frames pairs.  *frames_used (optional) receives the frame count of
- * the slowest pixel.  Requires a freshly reset context. */
+ * seed_pairs must hold max_frames pairs.  *frames_used (optional) receives the frames launched: the frame count
+ * of the slowest pixel rounded up to the launch size, at most max_frames.  A pixel's result depends on its own frames
+ * only, so the launches let a pixel whose wave waits for slower neighbours start on the frames of the next launch
+ * (the per-pixel lead lives in the device state for the duration of the call; PRT_RUN_AHEAD=0 turns it off); if
+ * max_frames is reached (PRT_ERR_NOT_READY) every unfrozen pixel has done exactly max_frames.
+ * Requires a freshly reset context. */
 int prt_render_spp(prt_ctx* ctx, uint32_t spp, uint32_t max_frames, const int32_t* seed_pairs,
                    uint32_t* frames_used);
 

@@ -58,6 +58,7 @@ struct prt_ctx {
     unsigned frames_per_launch = 512;
     // walk phases end below this many walking lanes (prt_set_walk_min_lanes): 1 -> 7.78, 4 -> 8.33, 6 -> 8.37, 8 -> 8.28, 12 -> 7.98
     uint32_t shadow_min_lanes = 0;                 // 0 = by tree size (frame_args); PRT_SHADOW_MIN_LANES
+    uint32_t run_ahead = 1;                        // FrameArgs::run_ahead of prt_render_spp's launches (PRT_RUN_AHEAD=0: off)
     uint32_t walk_min_lanes = 6;                   // FrameArgs::walk_min_lanes (prt_set_walk_min_lanes, PRT_WALK_MIN_LANES)
     prt_stats stats{};
     std::string err;
@@ -119,6 +120,7 @@ extern "C" int prt_create(int device, const prt_config* cfg, prt_ctx** out) {
         }
     c->stream = c->own_stream;
     if (const char* ev = std::getenv("PRT_FRAMES_PER_LAUNCH")) { const int k = std::atoi(ev); if (k >= 1) c->frames_per_launch = (unsigned)k; }
+    if (const char* ev = std::getenv("PRT_RUN_AHEAD")) c->run_ahead = std::atoi(ev) != 0 ? 1u : 0u;
     if (const char* ev = std::getenv("PRT_WALK_MIN_LANES")) { const int k = std::atoi(ev); if (k >= 1 && k <= 64) c->walk_min_lanes = (uint32_t)k; }
     if (const char* ev = std::getenv("PRT_SHADOW_MIN_LANES")) { const int k = std::atoi(ev); if (k >= 1 && k <= 64) c->shadow_min_lanes = (uint32_t)k; }
     *out = c;
@@ -319,6 +321,7 @@ static FrameArgs frame_args(prt_ctx* c, uint32_t first_frame, uint32_t n, const 
     fa.width = c->width; fa.full_height = c->full_height; fa.row0 = c->row0; fa.rows = c->rows;
     fa.block_rows = c->block_rows; fa.n_parts = c->n_parts; fa.part = c->part;
     fa.first_frame = first_frame; fa.n_frames = n; fa.seed_pairs = d_seeds; fa.spp_limit = spp;
+    fa.seed_frames = n; fa.run_ahead = 0;
     fa.unfinished = count ? c->d_counters : nullptr;
     fa.unfinished_host = nullptr;
     fa.tile_first = 0; fa.tile_stride = 1;
@@ -396,7 +399,9 @@ extern "C" int prt_render_spp(prt_ctx* c, uint32_t spp, uint32_t max_frames, con
         while (f < max_frames && unfinished) {
             const uint32_t n = (max_frames - f < step) ? max_frames - f : step;
             HIPCHK(c, hipMemsetAsync(c->d_counters, 0, sizeof(unsigned long long), c->stream));
-            c->variant = launch_render(c->sc, c->cam, c->S, frame_args(c, 1 + f, n, c->d_seeds + 2 * (size_t)f, spp, true), c->fb, c->stream);
+            FrameArgs fa = frame_args(c, 1 + f, n, c->d_seeds + 2 * (size_t)f, spp, true);
+            fa.seed_frames = max_frames - f; fa.run_ahead = c->run_ahead;
+            c->variant = launch_render(c->sc, c->cam, c->S, fa, c->fb, c->stream);
             ++c->stats.launches;
             f += n;
             HIPCHK(c, hipMemcpyAsync(&unfinished, c->d_counters, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
@@ -439,6 +444,7 @@ extern "C" int prt_render_spp(prt_ctx* c, uint32_t spp, uint32_t max_frames, con
                     const unsigned slot = issued[j] & 1u;
                     const uint32_t n = (max_frames - fj[j] < step) ? max_frames - fj[j] : step;
                     FrameArgs fa = frame_args(c, 1 + fj[j], n, c->d_seeds + 2 * (size_t)fj[j], spp, true);
+                    fa.seed_frames = max_frames - fj[j]; fa.run_ahead = c->run_ahead;
                     fa.unfinished = c->d_counters + 4 + 2 * j;
                     fa.unfinished_host = c->h_unfinished + 2 * j + slot;
                     fa.tile_first = (uint32_t)j; fa.tile_stride = (uint32_t)K;

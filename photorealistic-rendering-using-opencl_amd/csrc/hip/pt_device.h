@@ -1154,11 +1154,19 @@ PT_DEV void lane_init(Lane& L) {
 }
 
 // may this lane start (or go on with) a segment?  The "N spp" rule freezes a pixel at a segment boundary.
-PT_DEV bool lane_runnable(const FrameArgs& fa, const Lane& L) {
+// `laggards`: some lane of the wave still owes frames of this launch.  Then, in a launch that allows it (FrameArgs::run_ahead:
+// "N spp" mode, where a pixel's result does not depend on how many frames the others have done), a lane that has done its
+// n_frames starts further segments instead of idling -- frame numbers and seeds are its own, so its path is the same path.
+PT_DEV bool lane_owes_frames(const FrameArgs& fa, const Lane& L) {
+    if (L.stage != ST_READY || L.begun) return L.f < fa.n_frames;
+    if (fa.spp_limit && L.reset && L.samples >= fa.spp_limit) return false;
+    return L.f < fa.n_frames;
+}
+PT_DEV bool lane_runnable(const FrameArgs& fa, const Lane& L, const bool laggards) {
     if (L.stage != ST_READY) return false;
     if (L.begun) return true;
     if (fa.spp_limit && L.reset && L.samples >= fa.spp_limit) return false;
-    return L.f < fa.n_frames;
+    return L.f < fa.n_frames || (fa.run_ahead && laggards && L.f < fa.seed_frames);
 }
 
 // E (also reached straight from A by lanes that need no walk): the end of radiance() and of render_kernel.

@@ -76,6 +76,7 @@ __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene 
         L.diff = e.y & 0xffffu; L.spec = e.y >> 16;
         L.trans = e.z & 0xffffu; L.scatters = e.z >> 16;
         L.wasSpecular = (e.w & 1u) != 0; L.reset = (e.w & 2u) != 0;
+        L.f = e.w >> 2;                                         // frames of this launch done in an earlier one (run_ahead)
     }
     extern __shared__ unsigned lds_stack[];                     // sc.stack_levels x PT_BLOCK, sized by the launch
     TravStack stk;
@@ -84,11 +85,15 @@ __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene 
 #ifdef PT_PHASE_CLOCKS
     unsigned long long clk_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_readcyclecounter();
     const unsigned long long start_ = last_;
+    unsigned long long done_lanes_ = 0;
 #endif
     for (;;) {
-        const bool runnable = lane_runnable(fa, L);
+        const bool runnable = lane_runnable(fa, L, __any(lane_owes_frames(fa, L)));
         if (!__any(runnable || L.stage != ST_READY)) break;     // every lane has done its frames (or is frozen)
         PT_CLK(7);
+#ifdef PT_PHASE_CLOCKS
+        done_lanes_ += (unsigned long long)__popcll(__ballot(!runnable && L.stage == ST_READY));
+#endif
         if (runnable) lane_front<MATS, MEDIUM>(sc, cam, fa, L, gx, gy);                                  // A
         PT_CLK(0);
         {                                                                                                 // B
@@ -144,15 +149,19 @@ __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene 
         atomicMax(&g_phase_clocks[8], clk_[6]);
         atomicMax(&g_phase_clocks[9], last_ - start_);
         atomicAdd(&g_phase_clocks[10], 1ull);
+        atomicAdd(&g_phase_clocks[11], done_lanes_);
     }
 #endif
     if (L.f) {
+        // frames of the NEXT launch already done (run_ahead); a frozen pixel owes nothing and is ahead of nothing
+        const bool frozen = fa.spp_limit && L.reset && L.samples >= fa.spp_limit;
+        const unsigned frames_ahead = (!frozen && L.f > fa.n_frames) ? L.f - fa.n_frames : 0u;
         S.q0[id] = make_float4(L.origin.x, L.origin.y, L.origin.z, L.t);
         S.q1[id] = make_float4(L.dir.x, L.dir.y, L.dir.z, L.time);
         S.q2[id] = make_float4(L.mask.x, L.mask.y, L.mask.z, prt_u2f(L.total));
         S.q3[id] = make_float4(L.acc[0], L.acc[1], L.acc[2], L.acc[3]);
         S.q4[id] = make_uint4(L.samples, (L.diff & 0xffffu) | (L.spec << 16), (L.trans & 0xffffu) | (L.scatters << 16),
-                              (L.wasSpecular ? 1u : 0u) | (L.reset ? 2u : 0u));
+                              (L.wasSpecular ? 1u : 0u) | (L.reset ? 2u : 0u) | (frames_ahead << 2));
         const float ns = (float)L.samples;                                     // write_imagef, main.cl:159
         fb[id] = make_float4(L.acc[0] / ns, L.acc[1] / ns, L.acc[2] / ns, L.acc[3] / ns);
     }
@@ -369,6 +378,8 @@ void dump_phase_clocks() {
         else fprintf(stderr, "phase clocks: %-16s %5.1f %%\n", names[k], 100.0 * (double)h[k] / tot);
     if (h[10]) fprintf(stderr, "phase clocks: waves %llu, iterations per wave mean %.0f max %llu, cycles per wave mean %.0f max %llu\n", h[10],
                        (double)h[6] / (double)h[10], h[8], tot / (double)h[10], h[9]);
+    if (h[6]) fprintf(stderr, "phase clocks: lanes that have done their frames (or their samples) and wait for the wave: %.1f %% of the lane-iterations\n",
+                      100.0 * (double)h[11] / (64.0 * (double)h[6]));
 }
 #endif
 

@@ -115,14 +115,17 @@ struct DevState {
     float4* q1;   // dir.xyz, dist
     float4* q2;   // mask.xyz, bits(total)
     float4* q3;   // acc
-    uint4* q4;    // samples, diff | spec << 16, trans | scatters << 16, was_specular | reset << 1
+    uint4* q4;    // samples, diff | spec << 16, trans | scatters << 16, was_specular | reset << 1 | frames ahead << 2
 };
 
 struct FrameArgs {
     int width, full_height, row0, rows;     // tile of the image: `rows` local rows
     int block_rows, n_parts, part;          // local row ly -> global row row0 + (ly / B * n_parts + part) * B + ly % B
     uint32_t first_frame, n_frames;
-    const int32_t* seed_pairs;              // device, 2 * n_frames
+    const int32_t* seed_pairs;              // device, 2 * seed_frames
+    uint32_t seed_frames;                   // >= n_frames: frames from first_frame on that have seeds
+    uint32_t run_ahead;                     // "N spp" launches: a lane that has done its n_frames goes on (up to seed_frames) for as long
+                                            // as its wave waits for other lanes; how far it got is kept per pixel (DevState::q4.w >> 2)
     uint32_t spp_limit;
     unsigned long long* unfinished;         // device counter: pixels not yet frozen (spp mode), or null
     unsigned long long* unfinished_host;    // null: the host reads `unfinished` itself.  Else `unfinished` is a pair {count, waves

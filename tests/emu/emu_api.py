@@ -37,7 +37,7 @@ def lib():
         _lib.emu_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
-                                    C.c_uint32, C.c_uint32, C.c_uint32, C.c_char_p, C.c_int]
+                                    C.c_uint32, C.c_uint32, C.c_uint32, C.c_char_p, C.c_int, C.c_uint32, C.c_void_p]
         _lib.emu_selftest_fn.restype = None
         _lib.emu_selftest_fn.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     return _lib
@@ -52,12 +52,15 @@ def selftest_fn(fn, params, cases):
 
 
 def render(state_dtype, cfg, desc, camera, W, H, seed_pairs, first_frame=1, state=None, env=None, spp_limit=0,
-           walk_min_lanes=8, sched_seed=0, row0=0, rows=None, blocks=None, img=None):
-    """same call shape as oracle_api.Restatement.render"""
+           walk_min_lanes=8, sched_seed=0, row0=0, rows=None, blocks=None, img=None, window=None, ahead=None):
+    """same call shape as oracle_api.Restatement.render.  `window` / `ahead`: the launch covers the first `window` frames of
+    seed_pairs only, but (FrameArgs::run_ahead, "N spp" launches) a lane may go on into the rest while its wave waits for
+    others; `ahead` (uint32 per pixel, in / out) is how far each pixel is into the NEXT launch."""
     if blocks is not None:
         rows = sum(1 for r in range(H) if (r // blocks[0]) % blocks[1] == blocks[2])
     rows = H if rows is None else rows
-    n_frames = len(seed_pairs) // 2
+    seed_frames = len(seed_pairs) // 2
+    n_frames = seed_frames if window is None else min(window, seed_frames)
     if state is None:
         state = np.zeros(W * rows, dtype=state_dtype)
     if img is None:
@@ -72,7 +75,8 @@ def render(state_dtype, cfg, desc, camera, W, H, seed_pairs, first_frame=1, stat
     rc = lib().emu_render(C.cast(C.pointer(cfg), C.c_void_p), C.cast(C.pointer(desc), C.c_void_p), C.cast(C.pointer(camera), C.c_void_p),
                           envp, ew, eh, W, H, row0, rows, b[0], b[1], b[2], first_frame, n_frames,
                           seeds.ctypes.data_as(C.c_void_p), state.ctypes.data_as(C.c_void_p), img.ctypes.data_as(C.c_void_p),
-                          spp_limit, walk_min_lanes, sched_seed, err, 256)
+                          spp_limit, walk_min_lanes, sched_seed, err, 256, seed_frames,
+                          ahead.ctypes.data_as(C.c_void_p) if ahead is not None else None)
     if rc:
         raise RuntimeError("emu_render failed (%d): %s" % (rc, err.value.decode()))
     return state, img

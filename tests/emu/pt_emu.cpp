@@ -31,7 +31,7 @@ struct XorShift {
 
 template <unsigned MATS, bool MEDIUM>
 void run_tile(const DevScene& sc, const DevCamera& cam, const FrameArgs& fa, int tile_x, int tile_y, prt_path_state* state, float* out_rgba,
-              uint32_t sched_seed, std::vector<unsigned>& stack_mem) {
+              uint32_t sched_seed, std::vector<unsigned>& stack_mem, uint32_t* ahead) {
     Lane L[64];
     bool in_frame[64];
     int gxs[64] = {0}, gys[64] = {0};
@@ -53,6 +53,7 @@ void run_tile(const DevScene& sc, const DevCamera& cam, const FrameArgs& fa, int
         l.samples = r.samples;
         l.diff = r.diff; l.spec = r.spec; l.trans = r.trans; l.scatters = r.scatters;
         l.wasSpecular = r.was_specular != 0; l.reset = r.reset != 0;
+        if (ahead) l.f = ahead[ids[lane]];
     }
     stack_mem.assign((size_t)sc.stack_levels * 64, 0u);
     XorShift xs{sched_seed ? sched_seed * 2654435761u + (uint32_t)(tile_x * 7919 + tile_y) : 0u};
@@ -98,10 +99,11 @@ void run_tile(const DevScene& sc, const DevCamera& cam, const FrameArgs& fa, int
     };
 
     for (;;) {
-        bool any = false;
+        bool any = false, laggards = false;
         bool runnable[64];
+        for (int lane = 0; lane < 64; ++lane) laggards |= in_frame[lane] && lane_owes_frames(fa, L[lane]);
         for (int lane = 0; lane < 64; ++lane) {
-            runnable[lane] = in_frame[lane] && lane_runnable(fa, L[lane]);
+            runnable[lane] = in_frame[lane] && lane_runnable(fa, L[lane], laggards);
             any |= in_frame[lane] && (runnable[lane] || L[lane].stage != ST_READY);
         }
         if (!any) break;
@@ -129,6 +131,10 @@ void run_tile(const DevScene& sc, const DevCamera& cam, const FrameArgs& fa, int
         r.samples = l.samples;
         r.diff = (uint16_t)l.diff; r.spec = (uint16_t)l.spec; r.trans = (uint16_t)l.trans; r.scatters = (uint16_t)l.scatters;
         r.was_specular = l.wasSpecular ? 1 : 0; r.reset = l.reset ? 1 : 0;
+        if (ahead) {                                             // render_kernel keeps this in DevState::q4.w >> 2
+            const bool frozen = fa.spp_limit && l.reset && l.samples >= fa.spp_limit;
+            ahead[ids[lane]] = (!frozen && l.f > fa.n_frames) ? l.f - fa.n_frames : 0u;
+        }
         const float ns = (float)l.samples;
         float* px = out_rgba + 4 * ids[lane];
         for (int k = 0; k < 4; ++k) px[k] = l.acc[k] / ns;
@@ -141,7 +147,8 @@ void run_tile(const DevScene& sc, const DevCamera& cam, const FrameArgs& fa, int
 extern "C" int emu_render(const prt_config* cfg, const prt_scene_desc* desc, const prt_camera* camera, const float* env_rgb, int env_w, int env_h,
                           int width, int full_height, int row0, int rows, int block_rows, int n_parts, int part,
                           uint32_t first_frame, uint32_t n_frames, const int32_t* seed_pairs, prt_path_state* state, float* out_rgba,
-                          uint32_t spp_limit, uint32_t walk_min_lanes, uint32_t sched_seed, char* err, int err_len) {
+                          uint32_t spp_limit, uint32_t walk_min_lanes, uint32_t sched_seed, char* err, int err_len,
+                          uint32_t seed_frames, uint32_t* ahead) {   // ahead != null: FrameArgs::run_ahead, per-pixel frames ahead in / out
     PackedScene ps;
     std::string perr;
     const int rc = pack_scene(*cfg, desc, ps, perr);
@@ -160,6 +167,7 @@ extern "C" int emu_render(const prt_config* cfg, const prt_scene_desc* desc, con
     fa.width = width; fa.full_height = full_height; fa.row0 = row0; fa.rows = rows;
     fa.block_rows = block_rows > 0 ? block_rows : 1; fa.n_parts = n_parts > 0 ? n_parts : 1; fa.part = part;
     fa.first_frame = first_frame; fa.n_frames = n_frames; fa.seed_pairs = seed_pairs; fa.spp_limit = spp_limit;
+    fa.seed_frames = (ahead && seed_frames > n_frames) ? seed_frames : n_frames; fa.run_ahead = ahead ? 1u : 0u;
     fa.unfinished = nullptr; fa.unfinished_host = nullptr; fa.tile_first = 0; fa.tile_stride = 1;
     fa.walk_min_lanes = walk_min_lanes ? walk_min_lanes : 8;
     constexpr unsigned LD = PRT_MAT_LIGHT | PRT_MAT_DIFF;
@@ -169,14 +177,14 @@ extern "C" int emu_render(const prt_config* cfg, const prt_scene_desc* desc, con
         for (int tx = 0; tx < tiles_x; ++tx) {
             // the variant launch_render (pt_kernels.hip) picks
             if (sc.n_sdfs) {
-                if (!sc.has_medium) run_tile<PT_MATS_SDF, false>(sc, cam, fa, tx, ty, state, out_rgba, sched_seed, stack_mem);
-                else run_tile<PT_MATS_SDF, true>(sc, cam, fa, tx, ty, state, out_rgba, sched_seed, stack_mem);
+                if (!sc.has_medium) run_tile<PT_MATS_SDF, false>(sc, cam, fa, tx, ty, state, out_rgba, sched_seed, stack_mem, ahead);
+                else run_tile<PT_MATS_SDF, true>(sc, cam, fa, tx, ty, state, out_rgba, sched_seed, stack_mem, ahead);
             } else if (!sc.has_medium) {
-                if (sc.active_mats == LD) run_tile<LD, false>(sc, cam, fa, tx, ty, state, out_rgba, sched_seed, stack_mem);
-                else run_tile<0u, false>(sc, cam, fa, tx, ty, state, out_rgba, sched_seed, stack_mem);
+                if (sc.active_mats == LD) run_tile<LD, false>(sc, cam, fa, tx, ty, state, out_rgba, sched_seed, stack_mem, ahead);
+                else run_tile<0u, false>(sc, cam, fa, tx, ty, state, out_rgba, sched_seed, stack_mem, ahead);
             } else {
-                if (sc.active_mats == LD) run_tile<LD, true>(sc, cam, fa, tx, ty, state, out_rgba, sched_seed, stack_mem);
-                else run_tile<0u, true>(sc, cam, fa, tx, ty, state, out_rgba, sched_seed, stack_mem);
+                if (sc.active_mats == LD) run_tile<LD, true>(sc, cam, fa, tx, ty, state, out_rgba, sched_seed, stack_mem, ahead);
+                else run_tile<0u, true>(sc, cam, fa, tx, ty, state, out_rgba, sched_seed, stack_mem, ahead);
             }
         }
     return 0;

@@ -60,6 +60,19 @@ def test_spp_mode_and_batches_on_host(prt, oracle, emu):
                                 state=state, img=img, spp_limit=spp, sched_seed=99 + f)
     gstate = np.ascontiguousarray(g["state"]).view(oracle.PATH_STATE_DTYPE).reshape(-1)
     _same(oracle, gstate, g["image"], state, img, "spp golden")
+    # the same with FrameArgs::run_ahead, as prt_render_spp launches: a lane that has done the 32 frames of a launch goes on into
+    # the frames of the next ones while its wave waits for other lanes -- pixels end the launches at different frame numbers and
+    # still reach the same final state
+    state = img = None
+    ahead = np.zeros(W * H, dtype=np.uint32)
+    ran_ahead = 0
+    for f in range(0, maxf, 32):
+        state, img = emu.render(oracle.PATH_STATE_DTYPE, cfg, scene.desc, cam, W, H, seeds[2 * f:], first_frame=1 + f,
+                                state=state, img=img, spp_limit=spp, sched_seed=7 + f, walk_min_lanes=6, window=32, ahead=ahead)
+        ran_ahead += int((ahead > 0).sum())
+        assert int(ahead.max()) <= maxf - min(f + 32, maxf)
+    assert ran_ahead > 0 and not ahead.any()
+    _same(oracle, gstate, g["image"], state, img, "spp golden, lanes running ahead")
 
 
 @pytest.mark.parametrize("variant", ["cornell_mixed", "cornell_media_hg", "cornell_sdf"])
