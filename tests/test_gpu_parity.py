@@ -312,6 +312,10 @@ def test_spp_frame_budget_exhausted_then_render_again(prt, oracle, streams, monk
         r.render_spp(spp, prt.seed_pairs(12))       # 12 frames cannot finish 6 paths per pixel
     st = r.read_state()
     assert (st["samples"] >= 1).all() and not (st["samples"] == spp).all()
+    # lanes run ahead of their launch while their wave waits (8-frame launches here), but never past the seed table: what
+    # the caller finds is every pixel after exactly 12 frames of the "N spp" rule
+    ostate, oimg = oracle.Restatement().render(cfg, scene.desc, cam, W, H, prt.seed_pairs(12), env=env, spp_limit=spp)
+    _assert_same(oracle, ostate, oimg, st, r.read_framebuffer(), "exhausted spp call, streams=%s" % streams)
     r.reset()
     used = r.render_spp(spp, prt.seed_pairs(maxf))
     assert 0 < used <= maxf
