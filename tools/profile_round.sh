@@ -1,6 +1,6 @@
 #!/bin/bash
 # development helper: the rocprofv3 evidence of one round (kernel-trace stats of the default bench, HBM byte counters,
-# SQ / cache counters), written under gpurun_out/prof_round/ ; summaries are copied into profiles/ by hand
+# SQ / cache counters), written under gpurun_out/prof_round/ ; tools/profile_collect.py assembles profiles/ from them
 set -e
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_round
