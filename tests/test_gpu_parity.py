@@ -347,6 +347,25 @@ def test_internal_streams_are_invisible(prt, oracle, streams, monkeypatch):
     assert st.kernel_ms > 0 and st.kernel_sum_ms >= 0.5 * st.kernel_ms and st.launches >= int(streams)
     r.close()
 
+def test_run_ahead_is_invisible_at_full_size(prt, oracle, monkeypatch):
+    """prt_render_spp lets a lane that waits for its wave start on the next launch's frames (the lead is kept per pixel in the
+    state between launches).  BASELINE config 2's frame at 1920x1080, 24 spp in launches of 32 frames: with and without it
+    (PRT_RUN_AHEAD) the path state, the framebuffer and the work counters are the same bits -- and the lead is gone at the end."""
+    W, H, spp = 1920, 1080, 24
+    monkeypatch.setenv("PRT_FRAMES_PER_LAUNCH", "32")
+    out = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("PRT_RUN_AHEAD", flag)
+        scene, cfg, cam, env, r = _setup(prt, "cornell_diffuse", W, H)
+        used = r.render_spp(spp, prt.seed_pairs(spp * 16 + 64))
+        c = r.counts(spp)
+        out.append((r.read_state(), r.read_framebuffer(), c.segments, c.samples, c.finished_pixels, used, r.stats().launches))
+        r.close()
+    (s0, i0, seg0, smp0, fin0, used0, l0), (s1, i1, seg1, smp1, fin1, used1, l1) = out
+    _assert_same(oracle, s0, i0, s1, i1, "run-ahead on vs off")
+    assert (seg0, smp0, fin0) == (seg1, smp1, fin1) and fin1 == W * H and smp1 == spp * W * H
+    assert used1 <= used0 and l1 <= l0           # pixels that ran ahead finish in no more launches
+
 
 @pytest.mark.parametrize("variant", ["cornell_diffuse", "cornell_media_hg", "cornell_sdf"])
 def test_five_wave_kernel_variants_match_golden(prt, oracle, variant, monkeypatch):
