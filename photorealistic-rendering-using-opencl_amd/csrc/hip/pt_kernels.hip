@@ -38,12 +38,14 @@ using namespace dev;
 // One wave = one 8x8 tile; every lane runs the lane machine of pt_device.h on its pixel until it has done its n_frames
 // segments (or froze).  What is wave-level here is only the SCHEDULE: when the two walk phases of an iteration end.
 //   walk phase rule: go on while at least fa.walk_min_lanes (closest-hit phase) / fa.shadow_min_lanes (any-hit phase) lanes
-//   are still walking; below that, stop as soon as the iteration has something else to do (a lane finished its walk in
-//   this phase, or lanes are waiting in a later stage).  A lane cut off keeps its WalkState and LDS stack and resumes in
-//   the same phase of the next iteration.
+//   are still walking; below that, stop as soon as more lanes wait for the phase to end (they finished their walk in it, or
+//   sit in the stage behind it) than walk.  A lane cut off keeps its WalkState and LDS stack and resumes in the same phase
+//   of the next iteration.
+//   run-ahead ("N spp" launches, fa.run_ahead): a lane that has done its n_frames starts on the next launch's frames for as
+//   long as another lane of the wave still owes frames of this one; its lead goes into the state (q4.w >> 2).
 // WAVES = waves per SIMD the register allocator leaves room for.
 #ifdef PT_PHASE_CLOCKS                    // development builds: cycles of a wave per phase of the iteration (tools/phase_clocks.sh)
-__device__ unsigned long long g_phase_clocks[12];    // 8: most iterations of one wave, 9: longest wave (cycles), 10: waves, 11: first start .. last end
+__device__ unsigned long long g_phase_clocks[12];    // 0..5, 7 cycles per phase, 6 iterations; 8 most iterations of one wave, 9 longest wave (cycles), 10 waves, 11 idle lane-iterations
 #define PT_CLK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); clk_[k] += now_ - last_; last_ = now_; } while (0)
 #else
 #define PT_CLK(k) do { } while (0)
