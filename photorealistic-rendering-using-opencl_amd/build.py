@@ -42,6 +42,7 @@ def build(verbose=False, extra_hip_flags=()):
     for d, _, files in os.walk(CSRC):
         headers += [os.path.join(d, f) for f in files if f.endswith(".h")]
     headers += [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include"))]
+    headers.append(os.path.abspath(__file__))           # the flags live here
     objs = []
     for s in HOST_SOURCES + HIP_SOURCES:
         src = os.path.join(CSRC, s)
@@ -50,7 +51,9 @@ def build(verbose=False, extra_hip_flags=()):
         if not newer(src, obj, headers):
             continue
         if s in HIP_SOURCES:
-            cmd = [HIPCC] + COMMON + ["-x", "hip", "--offload-arch=" + ARCH] + list(extra_hip_flags)
+            # -fno-slp-vectorize: left on, the SLP vectorizer turns pairs of scalar float operations of the kernels into v_pk_*_f32
+            # with the register shuffling that takes -- same bits, 4 % slower
+            cmd = [HIPCC] + COMMON + ["-fno-slp-vectorize", "-x", "hip", "--offload-arch=" + ARCH] + list(extra_hip_flags)
         else:
             cmd = [HOSTCXX] + COMMON
         cmd += ["-c", src, "-o", obj]
