@@ -26,11 +26,15 @@ using namespace dev;
 #define PT_WAIT_RATIO 1u    // a walk phase is cut short only while more than this many lanes wait per lane still walking (0: while
                             // any lane waits -- the first form of the rule: 1.3 % slower on cornell, the same on the big mesh)
 #endif
+// waves per SIMD the register allocator must leave room for: 5 (96 VGPRs) -- without packed-float code (build.py:
+// -fno-slp-vectorize) the variants without a medium fit with 96 B of scratch and gain 3 ... 9 % over 4 waves; the medium variants
+// (more state per lane) lose 2 ... 7 % and stay at 4 (128 VGPRs) unless the tree is beyond one XCD's L2 or the scene raymarches
+// SDFs, where latency rules (+11 ... 13 %).  6 waves (80 VGPRs, 164 B of scratch): -13 %.
 #ifndef PT_BIG_WAVES
-#define PT_BIG_WAVES 5      // the same for trees beyond one XCD's L2 and for SDF scenes (96 VGPRs)
+#define PT_BIG_WAVES 5
 #endif
 #ifndef PT_MIN_WAVES
-#define PT_MIN_WAVES 4      // waves per SIMD the register allocator must leave room for (128 VGPRs)
+#define PT_MIN_WAVES 4
 #endif
 #define PT_BLOCK 64         // threads per workgroup: ONE wave.  A workgroup's slot (LDS, dispatch) frees only when its last wave
                             // ends, and waves over the mesh run ~3x longer than waves over a wall: one-wave groups +4 % over 256
@@ -357,13 +361,14 @@ template <unsigned MATS, bool MEDIUM>
 static void launch_variant(const DevScene& sc, const DevCamera& cam, const DevState& S, const FrameArgs& fa, float4* fb,
                            hipStream_t stream) {
     static const int forced = [] { const char* e = std::getenv("PRT_WAVES"); return e ? std::atoi(e) : 0; }();   // 4 / 5: override (tests, experiments)
-    // 5 waves where latency rules: the node records alone exceed one XCD's L2, or the scene raymarches SDFs (+11 %)
-    const bool big = forced ? forced >= 5 : (sc.n_pairs > 65536u || sc.n_sdfs != 0u);
-#ifndef PT_DEV_ONE_VARIANT
-    if (big) launch_variant_w<MATS, MEDIUM, PT_BIG_WAVES>(sc, cam, S, fa, fb, stream);
-    else
+    const bool five = forced ? forced >= 5 : (!MEDIUM || sc.n_pairs > 65536u || sc.n_sdfs != 0u);
+#ifdef PT_DEV_ONE_VARIANT
+    (void)five;
+    launch_variant_w<MATS, MEDIUM, PT_BIG_WAVES>(sc, cam, S, fa, fb, stream);
+#else
+    if (five) launch_variant_w<MATS, MEDIUM, PT_BIG_WAVES>(sc, cam, S, fa, fb, stream);
+    else launch_variant_w<MATS, MEDIUM, PT_MIN_WAVES>(sc, cam, S, fa, fb, stream);
 #endif
-    launch_variant_w<MATS, MEDIUM, PT_MIN_WAVES>(sc, cam, S, fa, fb, stream);
 }
 
 // Variant choice = the AOT analogue of the reference's per-scene program build (include/CL/cl_kernel.h):
