@@ -286,7 +286,7 @@ struct TravRes { bool found; float t; TriHit th; };
 // the fewest vector instructions per step.  The lane machine (lane_kernel) runs a wave's walks for a bounded number of
 // steps; a lane whose ray needs more keeps {node, sp, t, hit} for the wave's next walk phase, the LDS stack column
 // stays the lane's own.  found: (closest) a triangle was accepted, (any) a triangle closer than tmax exists.
-struct WalkState { unsigned node, sp; float t; TriHit th; bool found, done; };
+struct WalkState { unsigned node, sp; float t; TriHit th; unsigned found : 1, done : 1; };
 
 PT_DEV void walk_begin(const DevScene& sc, const bool ANY_HIT, const Ray& ray, const float tmax, const RayPre& p, WalkState& w,
                        const TravStack& stack) {
@@ -1101,7 +1101,7 @@ PT_DEV float power_heuristic(float pdf0, float pdf1) { return (pdf0 * pdf0) / (p
 //   * W3 is asked for last also at a medium scatter (the reference walks it before the probe): it only selects the
 //     radiance added to acc; no RNG draw or path state depends on it.
 // The RNG draws happen exactly in the reference's order.
-struct Hit { float t; f3 normal, pos; int mesh_id; bool didHit, backside; };
+struct Hit { float t; f3 normal, pos; int mesh_id; unsigned didHit : 1, backside : 1; };
 
 enum { K_NONE = 0, K_SURFACE_MIS = 1, K_SCATTER = 2 };
 enum { ST_READY = 0, ST_WALKC = 1, ST_BACK = 2, ST_WALKS = 3, ST_FINISH = 4 };
@@ -1110,36 +1110,41 @@ struct Lane {
     // the pixel's RTD record (kernels/main.cl:117-119; what prt_read_state shows between launches)
     f3 mask;
     float acc[4];
-    unsigned total, samples, diff, spec, trans, scatters;
-    bool wasSpecular, reset;
+    unsigned total, samples;
+    unsigned diff : 16, spec : 16;          // (16 bits each in the RTD record)
+    unsigned trans : 16, scatters : 16;
     // the segment's ray.  Inside a segment: Ray {origin, dir, t, time}; between segments the same four values ARE the
     // TempRay {origin, dir, time = ray.t, dist = ray.time} of rayToTemp (main.cl:28) -- lane_front swaps (t, time) where
     // tempToRay (main.cl:27) reads them back crosswise.
     f3 origin, dir;
     float t, time;
     Hit h;                   // closest hit of a ray: of (origin, dir) when h_valid; of the probe after W2
-    bool h_valid;
     Rng rng;
     // the scatter event at the segment's vertex (SurfaceScatterEvent, header.cl:208-215) that later phases need
     f3 wi, weight, n_shade;
     float pdf;
-    unsigned sampledLobe;
-    int mesh_id, kind;
-    bool terminate, w2_ran;
+    int mesh_id;
     f3 a;                    // MIS term of the probe ("a" of base.cl:170 / "b" of base.cl:259)
     f3 vis;                  // light-sample term if the shadow ray is unoccluded
     f3 sh_d;                 // shadow ray (origin: h.pos or ms_p)
     float sh_tmax;
-    bool sh;
     f3 ms_p, ps_w, ps_weight;   // medium scatter: position, phase-sampled direction and weight
     float ps_pdf;
     WalkState w;             // the walk in flight
     unsigned f;              // segments completed in this launch
-    int stage;
-    bool begun;              // seeds / restart of segment f done
-    bool fresh;              // the walk asked for has not started
-    bool w2;                 // the closest-hit walk in flight is the probe (W2), else the path ray (W1)
-    bool occluded;
+    // Flags and small integers share ONE register (bit-fields of one word): as members of their own each of them costs a
+    // VGPR for the whole life of the lane -- fourteen registers of the 96 a wave has at 5 waves per SIMD.
+    unsigned stage : 3;      // ST_*
+    unsigned kind : 2;       // K_*
+    unsigned sampledLobe : 8;
+    unsigned wasSpecular : 1, reset : 1;     // RTD
+    unsigned h_valid : 1;
+    unsigned terminate : 1, w2_ran : 1;
+    unsigned sh : 1;
+    unsigned begun : 1;      // seeds / restart of segment f done
+    unsigned fresh : 1;      // the walk asked for has not started
+    unsigned w2 : 1;         // the closest-hit walk in flight is the probe (W2), else the path ray (W1)
+    unsigned occluded : 1;
 };
 
 PT_DEV void lane_init(Lane& L) {

@@ -26,10 +26,11 @@ using namespace dev;
 #define PT_WAIT_RATIO 1u    // a walk phase is cut short only while more than this many lanes wait per lane still walking (0: while
                             // any lane waits -- the first form of the rule: 1.3 % slower on cornell, the same on the big mesh)
 #endif
-// waves per SIMD the register allocator must leave room for: 5 (96 VGPRs) -- without packed-float code (build.py:
-// -fno-slp-vectorize) the variants without a medium fit with 96 B of scratch and gain 3 ... 9 % over 4 waves; the medium variants
-// (more state per lane) lose 2 ... 7 % and stay at 4 (128 VGPRs) unless the tree is beyond one XCD's L2 or the scene raymarches
-// SDFs, where latency rules (+11 ... 13 %).  6 waves (80 VGPRs, 164 B of scratch): -13 %.
+// waves per SIMD the register allocator must leave room for: 5 (96 VGPRs).  Without packed-float code (build.py:
+// -fno-slp-vectorize) and with the lane's flags in one register (pt_device.h struct Lane) the variants without a medium gain
+// 4 ... 9 % over 4 waves (128 VGPRs); the medium variants carry more state per lane (isotropic +3 %, Henyey-Greenstein -4 %) and
+// stay at 4 unless the tree is beyond one XCD's L2 or the scene raymarches SDFs, where latency rules (+6 ... 13 %).  6 waves (80
+// VGPRs, 164 B of scratch): -13 %.
 #ifndef PT_BIG_WAVES
 #define PT_BIG_WAVES 5
 #endif
