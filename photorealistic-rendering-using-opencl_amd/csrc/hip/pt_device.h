@@ -214,7 +214,7 @@ PT_DEV RayPre ray_pre(const Ray& ray) {                          // bvh.cl:4-13 
     return p;
 }
 
-struct TriHit { float u, v, w; unsigned slot; };
+struct TriHit { float u, v; unsigned slot; };      // w = 1.0f - u - v is formed again where it is needed (the same expression, the same bits)
 
 // triangle.cl:4-43; `best_t` is ray->t.  The smooth normal (triangle.cl:30-34) is deferred to the
 // end of the traversal: it only depends on (u, v, w, slot) of the last accepted hit.
@@ -232,7 +232,7 @@ PT_DEV bool hit_triangle(const TriGeom* __restrict__ tg, unsigned slot, const Ra
         float t = dot(n, c) * inv_det;
         if (t > PT_EPS && t < best_t) {
             best_t = t;
-            th.u = u; th.v = v; th.w = w; th.slot = slot;
+            th.u = u; th.v = v; th.slot = slot;
             return true;
         }
     }
@@ -291,7 +291,7 @@ struct WalkState { unsigned node, sp; float t; TriHit th; unsigned found : 1, do
 PT_DEV void walk_begin(const DevScene& sc, const bool ANY_HIT, const Ray& ray, const float tmax, const RayPre& p, WalkState& w,
                        const TravStack& stack) {
     w.found = false; w.done = false; w.t = tmax;
-    w.th.u = w.th.v = w.th.w = 0.0f; w.th.slot = 0;
+    w.th.u = w.th.v = 0.0f; w.th.slot = 0;
     w.node = 0; w.sp = 0;
     if (sc.root_is_leaf) {                                       // tiny meshes: no tree to walk
         for (unsigned i = sc.root_leaf_first; i < sc.root_leaf_first + sc.root_leaf_count; ++i)
@@ -460,7 +460,7 @@ PT_DEV bool finish_closest(const DevScene& sc, Ray& ray, const TravRes& tr, int&
     if (tr.found) {
         const float4* nq = reinterpret_cast<const float4*>(sc.tri_nrm + tr.th.slot);
         const float4 a = nq[0], b = nq[1], c = nq[2];
-        ray.normal = F3(a.x, a.y, a.z) * tr.th.w + F3(b.x, b.y, b.z) * tr.th.u + F3(c.x, c.y, c.z) * tr.th.v;   // triangle.cl:30-34
+        ray.normal = F3(a.x, a.y, a.z) * (1.0f - tr.th.u - tr.th.v) + F3(b.x, b.y, b.z) * tr.th.u + F3(c.x, c.y, c.z) * tr.th.v;   // triangle.cl:22,30-34
     }
     ray.normal = normalize(ray.normal);
     ray.pos = ray.origin + ray.dir * t;
@@ -1121,13 +1121,19 @@ struct Lane {
     Hit h;                   // closest hit of a ray: of (origin, dir) when h_valid; of the probe after W2
     Rng rng;
     // the scatter event at the segment's vertex (SurfaceScatterEvent, header.cl:208-215) that later phases need
-    f3 wi, weight, n_shade;
-    float pdf;
+    f3 weight;
     int mesh_id;
     f3 a;                    // MIS term of the probe ("a" of base.cl:170 / "b" of base.cl:259)
-    f3 vis;                  // light-sample term if the shadow ray is unoccluded
-    f3 sh_d;                 // shadow ray (origin: h.pos or ms_p)
-    float sh_tmax;
+    // Two sets of seven words that are never alive together in one lane share their registers: {wi, n_shade, pdf} goes from
+    // lane_front to lane_back, which has read it into an Event before it writes {vis, sh_d, sh_tmax} for phases D and E.
+    union {
+        struct { f3 wi, n_shade; float pdf; };
+        struct {
+            f3 vis;          // light-sample term if the shadow ray is unoccluded
+            f3 sh_d;         // shadow ray (origin: h.pos or ms_p)
+            float sh_tmax;
+        };
+    };
     f3 ms_p, ps_w, ps_weight;   // medium scatter: position, phase-sampled direction and weight
     float ps_pdf;
     WalkState w;             // the walk in flight
@@ -1149,11 +1155,11 @@ struct Lane {
 
 PT_DEV void lane_init(Lane& L) {
     L.kind = K_NONE; L.mesh_id = -1; L.terminate = L.w2_ran = L.sh = false;
-    L.wi = L.weight = L.n_shade = L.a = L.vis = L.sh_d = L.ms_p = L.ps_w = L.ps_weight = splat(0.0f);
-    L.pdf = 1.0f; L.sampledLobe = 0u; L.sh_tmax = 0.0f; L.ps_pdf = 1.0f;
+    L.weight = L.a = L.vis = L.sh_d = L.ms_p = L.ps_w = L.ps_weight = splat(0.0f);
+    L.sampledLobe = 0u; L.sh_tmax = 0.0f; L.ps_pdf = 1.0f;
     L.rng.s0 = L.rng.s1 = 0u;
     L.h.t = 0.0f; L.h.normal = L.h.pos = splat(0.0f); L.h.mesh_id = -1; L.h.didHit = L.h.backside = false; L.h_valid = false;
-    L.w.node = L.w.sp = 0u; L.w.t = 0.0f; L.w.th.u = L.w.th.v = L.w.th.w = 0.0f; L.w.th.slot = 0u; L.w.found = false; L.w.done = true;
+    L.w.node = L.w.sp = 0u; L.w.t = 0.0f; L.w.th.u = L.w.th.v = 0.0f; L.w.th.slot = 0u; L.w.found = false; L.w.done = true;
     L.f = 0u; L.stage = ST_READY;
     L.begun = L.fresh = L.w2 = L.occluded = false;
 }
