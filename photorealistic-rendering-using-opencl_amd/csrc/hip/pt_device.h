@@ -1130,11 +1130,13 @@ struct Lane {
         struct { f3 wi, n_shade; float pdf; };
         struct {
             f3 vis;          // light-sample term if the shadow ray is unoccluded
-            f3 sh_d;         // shadow ray (origin: h.pos or ms_p)
+            f3 sh_d;         // shadow ray (origin: h.pos, or the scatter position)
             float sh_tmax;
         };
     };
-    f3 ms_p, ps_w, ps_weight;   // medium scatter: position, phase-sampled direction and weight
+    // a segment that scatters in the medium has no surface event: its position and phase-sampled direction ARE (origin, dir) from
+    // lane_front on (pathtracing.cl:58-59 assigns them at the end of the segment; nothing reads the old ray in between), the phase
+    // weight is `weight`; only the pdf of the phase sample needs a word of its own
     float ps_pdf;
     WalkState w;             // the walk in flight
     unsigned f;              // segments completed in this launch
@@ -1155,7 +1157,7 @@ struct Lane {
 
 PT_DEV void lane_init(Lane& L) {
     L.kind = K_NONE; L.mesh_id = -1; L.terminate = L.w2_ran = L.sh = false;
-    L.weight = L.a = L.vis = L.sh_d = L.ms_p = L.ps_w = L.ps_weight = splat(0.0f);
+    L.weight = L.a = L.vis = L.sh_d = splat(0.0f);
     L.sampledLobe = 0u; L.sh_tmax = 0.0f; L.ps_pdf = 1.0f;
     L.rng.s0 = L.rng.s1 = 0u;
     L.h.t = 0.0f; L.h.normal = L.h.pos = splat(0.0f); L.h.mesh_id = -1; L.h.didHit = L.h.backside = false; L.h_valid = false;
@@ -1190,9 +1192,7 @@ PT_DEV void lane_finish_segment(const DevScene& sc, Lane& L, f3 emission, const 
     } else if (MEDIUM && L.kind == K_SCATTER) {
         const f3 a = lit ? L.vis : splat(0.0f);
         emission = emission + (a + L.a) * L.mask;                        // pathtracing.cl:52-56
-        L.origin = L.ms_p;                                               // pathtracing.cl:58-61
-        L.dir = L.ps_w;
-        L.mask = L.mask * L.ps_weight;
+        L.mask = L.mask * L.weight;                                      // pathtracing.cl:58-61: origin, dir are in place (lane_front)
     }
     if (surface && !done) {                                              // handleSurface tail, base.cl:183-191
         L.wasSpecular = (L.sampledLobe & PRT_LOBE_SPECULAR) != 0;
@@ -1271,7 +1271,6 @@ PT_DEV void lane_front(const DevScene& sc, const DevCamera& cam, const FrameArgs
         L.mask = L.mask * ms.weight;
         if (!ms.exited && (int)L.scatters < sc.max_scattering_events) {
             L.kind = K_SCATTER;
-            L.ms_p = ms.p;
             L.scatters = (L.scatters + 1u) & 0xffffu;
             L.wasSpecular = false;
             // volumeLightSample, base.cl:194-230 (samples the light from ray.pos, not ms.p: SURVEY s9-Q4)
@@ -1289,7 +1288,7 @@ PT_DEV void lane_front(const DevScene& sc, const DevCamera& cam, const FrameArgs
             }
             PhaseSample ps;
             phase_sample(sc, ray.dir, ps, L.rng);                        // volumePhaseSample, base.cl:232-260
-            L.ps_w = ps.w; L.ps_weight = ps.weight; L.ps_pdf = ps.pdf;
+            L.origin = ms.p; L.dir = ps.w; L.weight = ps.weight; L.ps_pdf = ps.pdf;
             L.w2_ran = true;
             L.stage = ST_WALKC; L.fresh = true; L.w2 = true;
             return;
@@ -1337,7 +1336,7 @@ PT_DEV Ray lane_closest_ray(const Lane& L) {
     Ray r;
     r.pos = splat(0.0f); r.backside = false; r.t = PT_INF; r.time = 0.0f;
     if (MEDIUM && L.w2 && L.kind == K_SCATTER) {                          // volumePhaseSample's probe, base.cl:243-247
-        r.origin = L.ms_p; r.dir = L.ps_w; r.normal = splat(0.0f);
+        r.origin = L.origin; r.dir = L.dir; r.normal = splat(0.0f);
     } else {
         r.origin = L.origin; r.dir = L.dir;
         r.normal = L.w2 ? L.h.normal : splat(0.0f);                       // bsdfSample re-aims `ray` itself (base.cl:54-57); tempToRay zeroes it
@@ -1396,14 +1395,14 @@ PT_DEV void lane_back(const DevScene& sc, Lane& L) {
             }
         }
     } else if (MEDIUM && L.kind == K_SCATTER) {
-        sh_o = L.ms_p;
+        sh_o = L.origin;
         if (L.h.didHit) {
             const int mid = L.h.mesh_id;
             const unsigned lbits = sc.mats[mid + 1].bits;
             if (lbits & PRT_MAT_LIGHT) {
                 const Mat lm = load_mat(&sc.mats[mid + 1]);
                 const f3 tr = vexp(splat(sc.fog_sigma_t) * (-1.0f * L.h.t));
-                L.a = tr * lm.color * L.ps_weight * power_heuristic(L.ps_pdf, direct_pdf_mesh(sc, mid, L.ps_w, L.ms_p));   // "b" of base.cl:259
+                L.a = tr * lm.color * L.weight * power_heuristic(L.ps_pdf, direct_pdf_mesh(sc, mid, L.dir, L.origin));   // "b" of base.cl:259
             }
         }
     }
@@ -1417,7 +1416,7 @@ PT_DEV void lane_back(const DevScene& sc, Lane& L) {
 template <bool MEDIUM>
 PT_DEV Ray lane_shadow_ray(const Lane& L) {
     Ray r;
-    r.origin = (MEDIUM && L.kind == K_SCATTER) ? L.ms_p : L.h.pos;
+    r.origin = (MEDIUM && L.kind == K_SCATTER) ? L.origin : L.h.pos;
     r.dir = L.sh_d; r.normal = splat(0.0f); r.pos = splat(0.0f); r.t = L.sh_tmax; r.backside = false; r.time = 0.0f;
     return r;
 }

@@ -27,10 +27,9 @@ using namespace dev;
                             // any lane waits -- the first form of the rule: 1.3 % slower on cornell, the same on the big mesh)
 #endif
 // waves per SIMD the register allocator must leave room for: 5 (96 VGPRs).  Without packed-float code (build.py:
-// -fno-slp-vectorize) and with the lane's flags in one register (pt_device.h struct Lane) the variants without a medium gain
-// 4 ... 9 % over 4 waves (128 VGPRs); the medium variants carry more state per lane (isotropic +3 %, Henyey-Greenstein -4 %) and
-// stay at 4 unless the tree is beyond one XCD's L2 or the scene raymarches SDFs, where latency rules (+6 ... 13 %).  6 waves (80
-// VGPRs, 164 B of scratch): -13 %.
+// -fno-slp-vectorize), with the lane's flags in one register and its phase-exclusive fields sharing registers (pt_device.h struct
+// Lane) every variant gains over 4 waves (128 VGPRs): +4 ... 9 %.  6 waves (80 VGPRs, 164 B of scratch): -13 %.  PRT_WAVES=4
+// still selects the 128-register build (PT_MIN_WAVES).
 #ifndef PT_BIG_WAVES
 #define PT_BIG_WAVES 5
 #endif
@@ -362,7 +361,7 @@ template <unsigned MATS, bool MEDIUM>
 static void launch_variant(const DevScene& sc, const DevCamera& cam, const DevState& S, const FrameArgs& fa, float4* fb,
                            hipStream_t stream) {
     static const int forced = [] { const char* e = std::getenv("PRT_WAVES"); return e ? std::atoi(e) : 0; }();   // 4 / 5: override (tests, experiments)
-    const bool five = forced ? forced >= 5 : (!MEDIUM || sc.n_pairs > 65536u || sc.n_sdfs != 0u);
+    const bool five = forced ? forced >= 5 : true;
 #ifdef PT_DEV_ONE_VARIANT
     (void)five;
     launch_variant_w<MATS, MEDIUM, PT_BIG_WAVES>(sc, cam, S, fa, fb, stream);
