@@ -367,16 +367,18 @@ def test_run_ahead_is_invisible_at_full_size(prt, oracle, monkeypatch):
     assert used1 <= used0 and l1 <= l0           # pixels that ran ahead finish in no more launches
 
 
-@pytest.mark.parametrize("variant", ["cornell_diffuse", "cornell_media_hg", "cornell_sdf"])
-def test_five_wave_kernel_variants_match_golden(prt, oracle, variant, monkeypatch):
-    """big trees run the 96-register build of the kernel (5 waves/SIMD); forced here on the small scenes"""
-    monkeypatch.setenv("PRT_WAVES", "5")
+@pytest.mark.parametrize("waves", ["4", "6"])
+@pytest.mark.parametrize("variant", ["cornell_diffuse", "cornell_media_hg", "cornell_sdf", "cornell_mixed"])
+def test_other_wave_count_builds_match_golden(prt, oracle, variant, waves, monkeypatch):
+    """every kernel variant is built for 4, 5 and 6 waves per SIMD (128 / 96 / 80 registers): 5 is the default, big trees run
+    the 6-wave build; forced here on the small scenes"""
+    monkeypatch.setenv("PRT_WAVES", waves)
     g = np.load(os.path.join(GOLDEN, variant + ".npz"))
     W, H, frames = int(g["width"]), int(g["height"]), int(g["frames"])
     scene, cfg, cam, env, r = _setup(prt, variant, W, H)
     r.render_frames(prt.seed_pairs(frames))
     gstate = np.ascontiguousarray(g["state"]).view(oracle.PATH_STATE_DTYPE).reshape(-1)
-    _assert_same(oracle, gstate, g["image"], r.read_state(), r.read_framebuffer(), variant + " 5-wave build vs golden")
+    _assert_same(oracle, gstate, g["image"], r.read_state(), r.read_framebuffer(), variant + " %s-wave build vs golden" % waves)
     r.close()
 
 
