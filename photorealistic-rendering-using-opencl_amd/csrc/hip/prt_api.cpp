@@ -324,7 +324,7 @@ static FrameArgs frame_args(prt_ctx* c, uint32_t first_frame, uint32_t n, const 
     fa.seed_frames = n; fa.run_ahead = 0;
     fa.unfinished = count ? c->d_counters : nullptr;
     fa.unfinished_host = nullptr;
-    fa.tile_first = 0; fa.tile_stride = 1;
+    fa.tile_first = 0; fa.tile_stride = 1; fa.scatter = 0;
     fa.walk_min_lanes = c->walk_min_lanes;
     // Shadow rays: in a small tree 99 % end at the root and the rest is shallow -- cutting one off costs its pixel a whole
     // iteration, letting the wave finish them costs a few steps (cornell: 8.40 -> 8.68 G seg/s); through a big mesh they are

@@ -132,6 +132,7 @@ struct FrameArgs {
                                             // done}; the last wave of the launch writes the count here (pinned host memory) and
                                             // zeroes the pair for the next launch: no copy / fill kernels between launches
     uint32_t tile_first, tile_stride;       // this launch covers the tiles tile_first + k * tile_stride (sub-part of the frame)
+    uint32_t scatter;                       // set by the launcher: lane l of wave g renders pixel l of tile (l * waves + g) / 64 ...
     uint32_t walk_min_lanes;                // lane machine: a closest-hit walk phase of a wave ends once fewer lanes than this are still walking
     uint32_t shadow_min_lanes;              // ... and an any-hit (shadow ray) phase below this many
 };
