@@ -366,6 +366,33 @@ def test_run_ahead_is_invisible_at_full_size(prt, oracle, monkeypatch):
     assert (seg0, smp0, fin0) == (seg1, smp1, fin1) and fin1 == W * H and smp1 == spp * W * H
     assert used1 <= used0 and l1 <= l0           # pixels that ran ahead finish in no more launches
 
+@pytest.mark.parametrize("scatter", ["0", "1"])
+def test_pixel_to_wave_mappings_match_golden(prt, oracle, scatter, monkeypatch):
+    """a wave renders one 8x8 tile, or (launches with few rounds of waves) 64 pixels of 64 tiles spread over the launch: both
+    mappings forced here, on a ragged frame in interleaved row blocks (edge tiles: lanes outside the frame idle) and in spp mode"""
+    monkeypatch.setenv("PRT_SCATTER", scatter)
+    variant = "cornell_mixed"
+    g = np.load(os.path.join(GOLDEN, variant + ".npz"))
+    W, H, frames = int(g["width"]), int(g["height"]), int(g["frames"])
+    scene, cfg, cam, env, r = _setup(prt, variant, W, H)
+    r.render_frames(prt.seed_pairs(frames))
+    gstate = np.ascontiguousarray(g["state"]).view(oracle.PATH_STATE_DTYPE).reshape(-1)
+    _assert_same(oracle, gstate, g["image"], r.read_state(), r.read_framebuffer(), "scatter=%s vs golden" % scatter)
+    r.close()
+    W2, H2, frames2 = 61, 43, 20                                  # neither a multiple of 8
+    scene, cfg, cam2, env, r = _setup(prt, variant, W2, H2)
+    seeds = prt.seed_pairs(frames2)
+    ostate, oimg = oracle.Restatement().render(cfg, scene.desc, cam2, W2, H2, seeds, env=env)
+    r.render_frames(seeds)
+    _assert_same(oracle, ostate, oimg, r.read_state(), r.read_framebuffer(), "scatter=%s ragged frame" % scatter)
+    r.close()
+    gs = np.load(os.path.join(GOLDEN, "cornell_diffuse_spp.npz"))
+    scene, cfg, cam, env, r = _setup(prt, "cornell_diffuse", int(gs["width"]), int(gs["height"]))
+    r.render_spp(int(gs["spp"]), prt.seed_pairs(int(gs["frames"])))
+    sstate = np.ascontiguousarray(gs["state"]).view(oracle.PATH_STATE_DTYPE).reshape(-1)
+    _assert_same(oracle, sstate, gs["image"], r.read_state(), r.read_framebuffer(), "scatter=%s spp golden" % scatter)
+    r.close()
+
 
 @pytest.mark.parametrize("waves", ["4", "6"])
 @pytest.mark.parametrize("variant", ["cornell_diffuse", "cornell_media_hg", "cornell_sdf", "cornell_mixed"])
