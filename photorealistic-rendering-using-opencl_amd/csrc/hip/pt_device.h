@@ -1101,7 +1101,9 @@ PT_DEV float power_heuristic(float pdf0, float pdf1) { return (pdf0 * pdf0) / (p
 //   * W3 is asked for last also at a medium scatter (the reference walks it before the probe): it only selects the
 //     radiance added to acc; no RNG draw or path state depends on it.
 // The RNG draws happen exactly in the reference's order.
-struct Hit { float t; f3 normal, pos; int mesh_id; unsigned didHit : 1, backside : 1; };
+// (the hit POSITION is not kept: every branch of intersect_scene forms it as origin + dir * t with the final t -- finish_closest --
+// and the ray that was walked stays in the lane's (origin, dir) until the next segment re-aims it: lane_hit_pos forms it again)
+struct Hit { float t; f3 normal; int mesh_id; unsigned didHit : 1, backside : 1; };
 
 enum { K_NONE = 0, K_SURFACE_MIS = 1, K_SCATTER = 2 };
 enum { ST_READY = 0, ST_WALKC = 1, ST_BACK = 2, ST_WALKS = 3, ST_FINISH = 4 };
@@ -1155,12 +1157,15 @@ struct Lane {
     unsigned occluded : 1;
 };
 
+// position of the hit in L.h: intersect_scene's `ray.pos = ray.origin + ray.dir * t` (same operations, same bits) on the ray that was walked
+PT_DEV f3 lane_hit_pos(const Lane& L) { return L.origin + L.dir * L.h.t; }
+
 PT_DEV void lane_init(Lane& L) {
     L.kind = K_NONE; L.mesh_id = -1; L.terminate = L.w2_ran = L.sh = false;
     L.weight = L.a = L.vis = L.sh_d = splat(0.0f);
     L.sampledLobe = 0u; L.sh_tmax = 0.0f; L.ps_pdf = 1.0f;
     L.rng.s0 = L.rng.s1 = 0u;
-    L.h.t = 0.0f; L.h.normal = L.h.pos = splat(0.0f); L.h.mesh_id = -1; L.h.didHit = L.h.backside = false; L.h_valid = false;
+    L.h.t = 0.0f; L.h.normal = splat(0.0f); L.h.mesh_id = -1; L.h.didHit = L.h.backside = false; L.h_valid = false;
     L.w.node = L.w.sp = 0u; L.w.t = 0.0f; L.w.th.u = L.w.th.v = 0.0f; L.w.th.slot = 0u; L.w.found = false; L.w.done = true;
     L.f = 0u; L.stage = ST_READY;
     L.begun = L.fresh = L.w2 = L.occluded = false;
@@ -1255,7 +1260,7 @@ PT_DEV void lane_front(const DevScene& sc, const DevCamera& cam, const FrameArgs
     const unsigned am = active_mats<MATS>(sc);
     Ray ray;                                                             // the path ray with its hit
     ray.origin = L.origin; ray.dir = L.dir; ray.time = L.time;
-    ray.t = L.h.t; ray.normal = L.h.normal; ray.pos = L.h.pos; ray.backside = L.h.backside;
+    ray.t = L.h.t; ray.normal = L.h.normal; ray.pos = lane_hit_pos(L); ray.backside = L.h.backside;
     const bool didHit = L.h.didHit;
     L.mesh_id = L.h.mesh_id;
     L.t = L.h.t;
@@ -1352,7 +1357,7 @@ PT_DEV void lane_closest_done(const DevScene& sc, Lane& L) {
     Ray wr = lane_closest_ray<MEDIUM>(L);
     int mid;
     const bool hit = finish_closest<(MATS & PT_MATS_SDF) != 0>(sc, wr, r, mid);
-    L.h.t = wr.t; L.h.normal = wr.normal; L.h.pos = wr.pos; L.h.mesh_id = mid; L.h.didHit = hit; L.h.backside = wr.backside;
+    L.h.t = wr.t; L.h.normal = wr.normal; L.h.mesh_id = mid; L.h.didHit = hit; L.h.backside = wr.backside;
     L.h_valid = true;
     if (!L.w2) {
         L.stage = ST_READY;                                              // lane_front goes on with the hit in the next iteration
@@ -1365,7 +1370,8 @@ PT_DEV void lane_closest_done(const DevScene& sc, Lane& L) {
 // C
 template <unsigned MATS, bool MEDIUM>
 PT_DEV void lane_back(const DevScene& sc, Lane& L) {
-    f3 sh_o = L.h.pos;
+    const f3 hit_pos = lane_hit_pos(L);
+    f3 sh_o = hit_pos;
     if (L.kind == K_SURFACE_MIS) {
         const Mat mat = load_mat((L.mesh_id + 1) ? &sc.mats[L.mesh_id + 1] : &sc.mats[sc.n_meshes + 1]);
         if (L.w2_ran && L.h.didHit) {                                    // the probe ray, base.cl:58-75
@@ -1373,13 +1379,13 @@ PT_DEV void lane_back(const DevScene& sc, Lane& L) {
             const unsigned lbits = sc.mats[mid + 1].bits;
             if (lbits & PRT_MAT_LIGHT) {
                 const Mat lm = load_mat(&sc.mats[mid + 1]);
-                L.a = lm.color * L.weight * power_heuristic(L.pdf, direct_pdf_mesh(sc, mid, L.dir, L.h.pos));
+                L.a = lm.color * L.weight * power_heuristic(L.pdf, direct_pdf_mesh(sc, mid, L.dir, hit_pos));
                 if (MEDIUM) L.a = L.a * vexp(splat(sc.fog_sigma_t) * (-1.0f * L.t));
             }
         }
         // lightSample, base.cl:79-134 (from ray.pos = the probe ray's hit point: SURVEY s9-Q4)
         LightSample rec;
-        if (sample_light0(sc, L.h.pos, rec, L.rng)) {
+        if (sample_light0(sc, hit_pos, rec, L.rng)) {
             Event e;
             e.frame = make_frame(L.n_shade);
             e.wi = L.wi; e.weight = L.weight; e.pdf = L.pdf; e.sampledLobe = L.sampledLobe;
@@ -1416,7 +1422,7 @@ PT_DEV void lane_back(const DevScene& sc, Lane& L) {
 template <bool MEDIUM>
 PT_DEV Ray lane_shadow_ray(const Lane& L) {
     Ray r;
-    r.origin = (MEDIUM && L.kind == K_SCATTER) ? L.origin : L.h.pos;
+    r.origin = (MEDIUM && L.kind == K_SCATTER) ? L.origin : lane_hit_pos(L);
     r.dir = L.sh_d; r.normal = splat(0.0f); r.pos = splat(0.0f); r.t = L.sh_tmax; r.backside = false; r.time = 0.0f;
     return r;
 }
