@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PRT_ABI_VERSION 1
+#define PRT_ABI_VERSION 2
 #define PRT_MAX_LIGHTS 16
 
 typedef enum prt_status {
@@ -47,6 +47,10 @@ typedef enum prt_phase { PRT_PHASE_ISOTROPIC = 0, PRT_PHASE_HG = 1, PRT_PHASE_RA
  * The scene-specialisation parameters of the reference's kernel builder
  * (include/CL/cl_kernel.h:13-446 substitutes them into kernels/header.cl:39-122 as #defines).
  */
+#define PRT_VIEW_RESULTS 0u
+#define PRT_VIEW_NORMAL 1u
+#define PRT_VIEW_BVH_HIT 16u
+
 typedef struct prt_config {
     uint32_t abi_version;            /* PRT_ABI_VERSION */
     int32_t max_bounces;             /* cl_kernel.h:115-122   MAX_BOUNCES            (default 12) */
@@ -69,6 +73,11 @@ typedef struct prt_config {
     int32_t alpha_testing;           /* :56-63    -alpha */
     int32_t phase_function;          /* prt_phase */
     float phase_g;                   /* HG asymmetry; the reference fixes 0.6 */
+    uint32_t view_option;            /* kernels/main.cl:6-15 VIEW_OPTION: PRT_VIEW_RESULTS (0), or PRT_VIEW_NORMAL / PRT_VIEW_BVH_HIT:
+                                      * every frame overwrites the accumulator with (ray.normal after radiance(), 1) and the image is the
+                                      * accumulator itself (main.cl:143-145,150-152,161).  The other values of the reference's list are
+                                      * refused: VIEW_STACK_INDEX does not compile there (Ray has no bvh_stackIndex), VIEW_ALBEDO and
+                                      * VIEW_SPECULAR have no branch at all -- radiance() is never called and the image stays black */
 } prt_config;
 
 /* Host buffers of one scene, in the reference's layouts (src/main.cpp:93-122,401-418). */

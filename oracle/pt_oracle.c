@@ -1266,12 +1266,17 @@ static void render_pixel(Scene* sc, const prt_camera* cam, int width, int height
         if (st->reset) pto_tr_cur[3] |= 4;                               /* path ended in this segment */
     }
 #endif
-    st->acc[0] += r[0]; st->acc[1] += r[1]; st->acc[2] += r[2]; st->acc[3] += r[3];
+    const int view = sc->cfg->view_option == PRT_VIEW_NORMAL || sc->cfg->view_option == PRT_VIEW_BVH_HIT;
+    if (view) {                 /* main.cl:143-145,150-152: radiance() for its side effects, the accumulator shows ray.normal */
+        st->acc[0] = ray.normal.x; st->acc[1] = ray.normal.y; st->acc[2] = ray.normal.z; st->acc[3] = 1.0f;
+    } else {
+        st->acc[0] += r[0]; st->acc[1] += r[1]; st->acc[2] += r[2]; st->acc[3] += r[3];
+    }
     st->origin[0] = ray.origin.x; st->origin[1] = ray.origin.y; st->origin[2] = ray.origin.z;   /* rayToTemp, main.cl:28 */
     st->dir[0] = ray.dir.x; st->dir[1] = ray.dir.y; st->dir[2] = ray.dir.z;
     st->time = ray.t;           /* positional initialiser { origin, dir, ray.t, ray.time } into { origin, dir, time, dist } */
     st->dist = ray.time;
-    const float ns = (float)st->samples;
+    const float ns = view ? 1.0f : (float)st->samples;         /* main.cl:158-162: a debug view writes the accumulator as it is */
     pixel_rgba[0] = st->acc[0] / ns; pixel_rgba[1] = st->acc[1] / ns; pixel_rgba[2] = st->acc[2] / ns; pixel_rgba[3] = st->acc[3] / ns;
 }
 

@@ -96,13 +96,17 @@ def build_support(tmp):
     return objs
 
 
-def build_variant(name, scene, width, height, alpha, shadow_stack, phase, blob_dir, exe, tmp, support, kat=False):
+def build_variant(name, scene, width, height, alpha, shadow_stack, phase, blob_dir, exe, tmp, support, kat=False, view=""):
     cl = os.path.join(tmp, name + ".cl")
     blob = os.path.join(blob_dir, name + ".sceneblob")
     run([exe, os.path.abspath(scene), str(width), str(height), "1" if alpha else "0", cl, blob],
         cwd=os.path.join(tmp, "run"))
-    if shadow_stack or kat:
+    if shadow_stack or kat or view:
         text = open(cl).read()
+        if view:    # the debug views are a source-level switch of kernels/main.cl:15 (VIEW_OPTION ... & VIEW_RESULTS): flip it in the temp text
+            needle = "#define VIEW_OPTION (~(0xFF<<(DEBUG*8)) & VIEW_RESULTS)"
+            assert text.count(needle) == 1, "VIEW_OPTION define not found exactly once"
+            text = text.replace(needle, "#define VIEW_OPTION (~(0xFF<<(DEBUG*8)) & %s)" % view)
         if shadow_stack:
             needle = "#define STACK_SIZE 8\n"
             assert text.count(needle) == 1, "shadow stack define not found exactly once"
@@ -130,6 +134,8 @@ def main():
     ap.add_argument("--shadow-stack", type=int, default=64)
     ap.add_argument("--phase", default="", choices=["", "isotropic", "hg", "rayleigh"], help="phase function of the global medium")
     ap.add_argument("--blob-dir", default=os.path.join(ROOT, "tests", "golden"))
+    ap.add_argument("--view", default="", choices=["", "VIEW_NORMAL", "VIEW_ALBEDO", "VIEW_SPECULAR", "VIEW_BVH_HIT"],
+                    help="debug view of kernels/main.cl:6-15 (VIEW_STACK_INDEX does not compile: Ray has no bvh_stackIndex)")
     ap.add_argument("--kat", action="store_true", help="append oracle/ref/kat_harness.cl (per-function known-answer entry point kat_run)")
     a = ap.parse_args()
     if not os.path.isdir(REF):
@@ -144,7 +150,7 @@ def main():
         for v in a.variant:
             name, scene = v.split("=", 1)
             so = build_variant(name, scene, a.width, a.height, a.alpha, a.shadow_stack, a.phase,
-                               a.blob_dir, exe, tmp, support, kat=a.kat)
+                               a.blob_dir, exe, tmp, support, kat=a.kat, view=a.view)
             print("built", so)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

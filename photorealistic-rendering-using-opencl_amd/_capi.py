@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PRT_LIB", os.path.join(HERE, "libprt.so"))   # PRT_LIB: A/B builds of the same product
 
 PRT_MAX_LIGHTS = 16
-PRT_ABI_VERSION = 1
+PRT_ABI_VERSION = 2
 
 
 class Material(C.Structure):
@@ -45,7 +45,8 @@ class Config(C.Structure):
                 ("light_indices", C.c_uint32 * PRT_MAX_LIGHTS),
                 ("has_global_medium", C.c_int32), ("fog_density", C.c_float), ("fog_sigma_a", C.c_float),
                 ("fog_sigma_s", C.c_float), ("fog_sigma_t", C.c_float), ("fog_abs_only", C.c_int32),
-                ("alpha_testing", C.c_int32), ("phase_function", C.c_int32), ("phase_g", C.c_float)]
+                ("alpha_testing", C.c_int32), ("phase_function", C.c_int32), ("phase_g", C.c_float),
+                ("view_option", C.c_uint32)]
 
 
 class SceneDesc(C.Structure):

@@ -928,8 +928,11 @@ PT_DEV float coat_pdf(const Event& e, const Mat& mat) {
 // ---- dispatch, kernels/bxdf/bxdf.cl:57-273.  MATS = compile-time ACTIVE_MATS (0 = run-time); the
 // PT_MATS_SDF bit marks the variants that carry the raymarched primitives (H_SDF scenes only) ---------
 #define PT_MATS_SDF 0x80000000u
+// PT_MATS_VIEW bit: the debug views VIEW_NORMAL / VIEW_BVH_HIT of kernels/main.cl:6-15,143-152 (prt_config::view_option)
+#define PT_MATS_VIEW 0x40000000u
+#define PT_MATS_FLAGS (PT_MATS_SDF | PT_MATS_VIEW)
 template <unsigned MATS>
-PT_DEV unsigned active_mats(const DevScene& sc) { return (MATS & ~PT_MATS_SDF) ? (MATS & ~PT_MATS_SDF) : sc.active_mats; }
+PT_DEV unsigned active_mats(const DevScene& sc) { return (MATS & ~PT_MATS_FLAGS) ? (MATS & ~PT_MATS_FLAGS) : sc.active_mats; }
 
 template <unsigned MATS>
 PT_DEV bool bsdf_sample2(const DevScene& sc, Event& e, const Ray& ray, const Mat& mat, Rng& rng) {
@@ -1141,6 +1144,7 @@ struct Lane {
     // weight is `weight`; only the pdf of the phase sample needs a word of its own
     float ps_pdf;
     WalkState w;             // the walk in flight
+    f3 view_n;               // PT_MATS_VIEW variants only: ray.normal as render_kernel finds it after radiance() (main.cl:143-145)
     unsigned f;              // segments completed in this launch
     // Flags and small integers share ONE register (bit-fields of one word): as members of their own each of them costs a
     // VGPR for the whole life of the lane -- fourteen registers of the 96 a wave has at 5 waves per SIMD.
@@ -1189,7 +1193,7 @@ PT_DEV bool lane_runnable(const FrameArgs& fa, const Lane& L, const bool laggard
 
 // E (also reached straight from A by lanes that need no walk): the end of radiance() and of render_kernel.
 // `surface`: handleSurface sampled a direction (base.cl:183-191 still to do); `lit`: the shadow ray was unoccluded.
-template <bool MEDIUM>
+template <unsigned MATS, bool MEDIUM>
 PT_DEV void lane_finish_segment(const DevScene& sc, Lane& L, f3 emission, const float alpha, const bool surface, bool done, const bool lit) {
     if (L.kind == K_SURFACE_MIS) {
         const f3 b = lit ? L.vis : splat(0.0f);
@@ -1225,7 +1229,8 @@ PT_DEV void lane_finish_segment(const DevScene& sc, Lane& L, f3 emission, const 
             (int)L.spec >= sc.max_spec_bounces || (int)L.trans >= sc.max_trans_bounces)
             L.reset = true;                                              // pathtracing.cl:109-115
     }
-    L.acc[0] += emission.x; L.acc[1] += emission.y; L.acc[2] += emission.z; L.acc[3] += alpha;   // main.cl:142
+    if (MATS & PT_MATS_VIEW) { L.acc[0] = L.view_n.x; L.acc[1] = L.view_n.y; L.acc[2] = L.view_n.z; L.acc[3] = 1.0f; }   // main.cl:143-145,150-152
+    else { L.acc[0] += emission.x; L.acc[1] += emission.y; L.acc[2] += emission.z; L.acc[3] += alpha; }   // main.cl:142
     // rayToTemp (main.cl:28): {origin, dir, ray.t, ray.time} are already where the next segment finds them
     ++L.f;
     L.begun = false;
@@ -1261,6 +1266,10 @@ PT_DEV void lane_front(const DevScene& sc, const DevCamera& cam, const FrameArgs
     Ray ray;                                                             // the path ray with its hit
     ray.origin = L.origin; ray.dir = L.dir; ray.time = L.time;
     ray.t = L.h.t; ray.normal = L.h.normal; ray.pos = lane_hit_pos(L); ray.backside = L.h.backside;
+    // what a segment without a probe of `ray` itself leaves in ray.normal.  The hit may come from the previous segment's probe,
+    // which entered intersect_scene with that segment's normal in `ray`; the reference walks the ray again from tempToRay's zero
+    // normal, and where nothing is hit that input is all intersect_scene has: normalize(0)
+    if (MATS & PT_MATS_VIEW) L.view_n = L.h.didHit ? ray.normal : normalize(splat(0.0f));
     const bool didHit = L.h.didHit;
     L.mesh_id = L.h.mesh_id;
     L.t = L.h.t;
@@ -1303,13 +1312,13 @@ PT_DEV void lane_front(const DevScene& sc, const DevCamera& cam, const FrameArgs
         L.reset = true;
         if (sc.alpha_testing) { emission = splat(0.0f); alpha = 0.0f; }
         else emission = L.mask * env_lookup(sc, ray.dir);
-        lane_finish_segment<MEDIUM>(sc, L, emission, alpha, false, true, false);
+        lane_finish_segment<MATS, MEDIUM>(sc, L, emission, alpha, false, true, false);
         return;
     }
     if ((am & PRT_MAT_LIGHT) && (mat.t & PRT_MAT_LIGHT)) {               // pathtracing.cl:77-84
         if (L.wasSpecular) emission = emission + mat.color * L.mask;
         L.reset = true;
-        lane_finish_segment<MEDIUM>(sc, L, emission, alpha, false, true, false);
+        lane_finish_segment<MATS, MEDIUM>(sc, L, emission, alpha, false, true, false);
         return;
     }
     Event e;                                                             // makeLocalScatterEvent, base.cl:11-14
@@ -1328,10 +1337,10 @@ PT_DEV void lane_front(const DevScene& sc, const DevCamera& cam, const FrameArgs
         if (ok) { L.w2_ran = true; L.stage = ST_WALKC; L.fresh = true; L.w2 = true; }
         else { L.terminate = true; L.stage = ST_BACK; }
     } else if (ok) {
-        lane_finish_segment<MEDIUM>(sc, L, emission, alpha, true, false, false);
+        lane_finish_segment<MATS, MEDIUM>(sc, L, emission, alpha, true, false, false);
     } else {
         L.reset = true;
-        lane_finish_segment<MEDIUM>(sc, L, emission, alpha, false, true, false);
+        lane_finish_segment<MATS, MEDIUM>(sc, L, emission, alpha, false, true, false);
     }
 }
 
@@ -1359,6 +1368,7 @@ PT_DEV void lane_closest_done(const DevScene& sc, Lane& L) {
     const bool hit = finish_closest<(MATS & PT_MATS_SDF) != 0>(sc, wr, r, mid);
     L.h.t = wr.t; L.h.normal = wr.normal; L.h.mesh_id = mid; L.h.didHit = hit; L.h.backside = wr.backside;
     L.h_valid = true;
+    if ((MATS & PT_MATS_VIEW) && L.w2 && !(MEDIUM && L.kind == K_SCATTER)) L.view_n = wr.normal;   // bsdfSample's intersect_scene works on `ray` itself
     if (!L.w2) {
         L.stage = ST_READY;                                              // lane_front goes on with the hit in the next iteration
     } else {
@@ -1428,9 +1438,9 @@ PT_DEV Ray lane_shadow_ray(const Lane& L) {
 }
 
 // E
-template <bool MEDIUM>
+template <unsigned MATS, bool MEDIUM>
 PT_DEV void lane_finish(const DevScene& sc, Lane& L) {
-    lane_finish_segment<MEDIUM>(sc, L, splat(0.0f), 1.0f, L.kind == K_SURFACE_MIS, false, L.sh && !L.occluded);
+    lane_finish_segment<MATS, MEDIUM>(sc, L, splat(0.0f), 1.0f, L.kind == K_SURFACE_MIS, false, L.sh && !L.occluded);
 }
 
 }  // namespace dev

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene 
             if (walking && L.w.done) { L.occluded = L.w.found; L.stage = ST_FINISH; }
         }
         PT_CLK(4);
-        if (L.stage == ST_FINISH) lane_finish<MEDIUM>(sc, L);                                            // E
+        if (L.stage == ST_FINISH) lane_finish<MATS, MEDIUM>(sc, L);                                            // E
         PT_CLK(5);
 #ifdef PT_PHASE_CLOCKS
         ++clk_[6];
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene 
         S.q3[id] = make_float4(L.acc[0], L.acc[1], L.acc[2], L.acc[3]);
         S.q4[id] = make_uint4(L.samples, (L.diff & 0xffffu) | (L.spec << 16), (L.trans & 0xffffu) | (L.scatters << 16),
                               (L.wasSpecular ? 1u : 0u) | (L.reset ? 2u : 0u) | (frames_ahead << 2));
-        const float ns = (float)L.samples;                                     // write_imagef, main.cl:159
+        const float ns = (MATS & PT_MATS_VIEW) ? 1.0f : (float)L.samples;      // write_imagef, main.cl:159 (a debug view: :161)
         fb[id] = make_float4(L.acc[0] / ns, L.acc[1] / ns, L.acc[2] / ns, L.acc[3] / ns);
     }
     if (fa.unfinished) {
@@ -416,6 +416,17 @@ const char* launch_render(const DevScene& sc, const DevCamera& cam, const DevSta
     launch_variant<LD, false>(sc, cam, S, fa, fb, stream);
     return "render_kernel<LIGHT|DIFF>";
 #else
+    if (sc.view) {                        // the debug views: generic material set, the default wave count only
+        constexpr unsigned V = PT_MATS_VIEW, VS = PT_MATS_VIEW | PT_MATS_SDF;
+        if (sc.n_sdfs) {
+            if (!sc.has_medium) launch_variant_w<VS, false, PT_WAVES>(sc, cam, S, fa, fb, stream);
+            else launch_variant_w<VS, true, PT_WAVES>(sc, cam, S, fa, fb, stream);
+        } else {
+            if (!sc.has_medium) launch_variant_w<V, false, PT_WAVES>(sc, cam, S, fa, fb, stream);
+            else launch_variant_w<V, true, PT_WAVES>(sc, cam, S, fa, fb, stream);
+        }
+        return "render_kernel<generic,view>";
+    }
     if (sc.n_sdfs) {                      // H_SDF scenes: the generic variants that carry the raymarcher
         if (!sc.has_medium) { launch_variant<PT_MATS_SDF, false>(sc, cam, S, fa, fb, stream); return "render_kernel<generic,sdf>"; }
         launch_variant<PT_MATS_SDF, true>(sc, cam, S, fa, fb, stream);

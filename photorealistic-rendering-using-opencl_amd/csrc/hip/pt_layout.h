@@ -97,6 +97,7 @@ struct DevScene {
     int has_medium, fog_abs_only, alpha_testing, phase_function;
     float fog_sigma_s, fog_sigma_t, phase_g;
     uint32_t ntrans_mask;
+    uint32_t view;                  // prt_config::view_option is PRT_VIEW_NORMAL or PRT_VIEW_BVH_HIT (the PT_MATS_VIEW kernel variants)
 };
 
 // camera.cl:19-28 evaluated once per prt_set_camera (pt_device.h camera_basis), not per path start

@@ -189,6 +189,10 @@ int pack_scene(const prt_config& cfg, const prt_scene_desc* s, PackedScene& out,
     sc.has_medium = cfg.has_global_medium; sc.fog_abs_only = cfg.fog_abs_only; sc.alpha_testing = cfg.alpha_testing;
     sc.phase_function = cfg.phase_function; sc.fog_sigma_s = cfg.fog_sigma_s; sc.fog_sigma_t = cfg.fog_sigma_t; sc.phase_g = cfg.phase_g;
     sc.ntrans_mask = cfg.active_mats & (PRT_MAT_DIEL | PRT_MAT_ROUGH_DIEL);
+    if (cfg.view_option != PRT_VIEW_RESULTS && cfg.view_option != PRT_VIEW_NORMAL && cfg.view_option != PRT_VIEW_BVH_HIT)
+        return fail(c, PRT_ERR_UNSUPPORTED, "prt_upload_scene: view_option: only PRT_VIEW_RESULTS, PRT_VIEW_NORMAL and PRT_VIEW_BVH_HIT render "
+                                            "anything in the reference (VIEW_STACK_INDEX does not compile, VIEW_ALBEDO / VIEW_SPECULAR never call radiance())");
+    sc.view = cfg.view_option != PRT_VIEW_RESULTS;
     out.sc = sc;
     return PRT_OK;
 }

@@ -85,6 +85,7 @@ int main(int argc, char** argv) {
     std::string models_directory = "../resources/models/";        // :35
     std::string env_map_filepath, out_path = "render.pfm";
     bool alpha = false;
+    uint32_t view = PRT_VIEW_RESULTS;                              // kernels/main.cl:15: a source edit in the reference, a flag here
     unsigned frames = 0, spp = 16;
     int device = 0;
     for (int i = 1; i < argc; ++i) {
@@ -95,6 +96,7 @@ int main(int argc, char** argv) {
         else if (a == "-height") window_height = std::atoi(next());
         else if (a == "-hdr") env_map_filepath = next();
         else if (a == "-alpha") alpha = true;
+        else if (a == "-view") { const std::string v = next(); view = v == "normal" ? PRT_VIEW_NORMAL : v == "bvh_hit" ? PRT_VIEW_BVH_HIT : PRT_VIEW_RESULTS; }
         else if (a == "-encoder") next();                          // PNG/HDR encoder choice of the GL path: ignored
         else if (a == "-models") models_directory = next();
         else if (a == "-frames") frames = (unsigned)std::atoi(next());
@@ -107,6 +109,7 @@ int main(int argc, char** argv) {
         prt::host_scene scene;
         scene.load(scene_filepath);                                // :375-376
         prt_config cfg = scene.make_config(alpha);
+        cfg.view_option = view;
         CHECK(prt_create(device, &cfg, &ctx));                     // initOpenCL(), :380
 
         std::vector<float> vertices4, normals4;

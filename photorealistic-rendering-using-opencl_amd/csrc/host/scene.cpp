@@ -235,6 +235,7 @@ prt_config host_scene::make_config(bool alpha_testing) const {
     c.alpha_testing = alpha_testing ? 1 : 0;
     c.phase_function = PRT_PHASE_ISOTROPIC;       // kernels/media.cl:61
     c.phase_g = 0.6f;                             // kernels/phasefunctions/HenyeyGreenstein.cl:4
+    c.view_option = PRT_VIEW_RESULTS;             // kernels/main.cl:15
     return c;
 }
 

@@ -54,6 +54,8 @@ VARIANTS = {
     "cornell_absfog": ("cornell_absfog.json", 0, False),        # absorption-only medium
     "cornell_fogcap": ("cornell_fogcap.json", 1, True),         # dense HG medium running into MAX_SCATTERING_EVENTS
 }
+# debug views of kernels/main.cl:6-15 (prt_config::view_option): fixture -> (base variant, view_option)
+VIEW_VARIANTS = {"cornell_mixed_viewnormal": ("cornell_mixed", 1), "cornell_media_hg_viewbvh": ("cornell_media_hg", 16)}
 PINHOLE_VARIANTS = {"cornell_edge"}                             # apertureRadius 0: camera.cl:44-56 takes the pinhole branch
 ALPHA_VARIANTS = {"cornell_quadlight"}                          # built / run with ALPHA_TESTING (the reference's -alpha flag)
 

@@ -118,7 +118,7 @@ void run_tile(const DevScene& sc, const DevCamera& cam, const FrameArgs& fa, int
         for (int lane = 0; lane < 64; ++lane)
             if (in_frame[lane] && L[lane].stage == ST_WALKS && L[lane].w.done) { L[lane].occluded = L[lane].w.found; L[lane].stage = ST_FINISH; }
         for (int lane = 0; lane < 64; ++lane)
-            if (in_frame[lane] && L[lane].stage == ST_FINISH) lane_finish<MEDIUM>(sc, L[lane]);
+            if (in_frame[lane] && L[lane].stage == ST_FINISH) lane_finish<MATS, MEDIUM>(sc, L[lane]);
     }
     for (int lane = 0; lane < 64; ++lane) {
         if (!in_frame[lane] || !L[lane].f) continue;
@@ -135,7 +135,7 @@ void run_tile(const DevScene& sc, const DevCamera& cam, const FrameArgs& fa, int
             const bool frozen = fa.spp_limit && l.reset && l.samples >= fa.spp_limit;
             ahead[ids[lane]] = (!frozen && l.f > fa.n_frames) ? l.f - fa.n_frames : 0u;
         }
-        const float ns = (float)l.samples;
+        const float ns = (MATS & PT_MATS_VIEW) ? 1.0f : (float)l.samples;
         float* px = out_rgba + 4 * ids[lane];
         for (int k = 0; k < 4; ++k) px[k] = l.acc[k] / ns;
     }
@@ -176,7 +176,16 @@ extern "C" int emu_render(const prt_config* cfg, const prt_scene_desc* desc, con
     for (int ty = 0; ty < tiles_y; ++ty)
         for (int tx = 0; tx < tiles_x; ++tx) {
             // the variant launch_render (pt_kernels.hip) picks
-            if (sc.n_sdfs) {
+            if (sc.view) {
+                constexpr unsigned V = PT_MATS_VIEW, VS = PT_MATS_VIEW | PT_MATS_SDF;
+                if (sc.n_sdfs) {
+                    if (!sc.has_medium) run_tile<VS, false>(sc, cam, fa, tx, ty, state, out_rgba, sched_seed, stack_mem, ahead);
+                    else run_tile<VS, true>(sc, cam, fa, tx, ty, state, out_rgba, sched_seed, stack_mem, ahead);
+                } else {
+                    if (!sc.has_medium) run_tile<V, false>(sc, cam, fa, tx, ty, state, out_rgba, sched_seed, stack_mem, ahead);
+                    else run_tile<V, true>(sc, cam, fa, tx, ty, state, out_rgba, sched_seed, stack_mem, ahead);
+                }
+            } else if (sc.n_sdfs) {
                 if (!sc.has_medium) run_tile<PT_MATS_SDF, false>(sc, cam, fa, tx, ty, state, out_rgba, sched_seed, stack_mem, ahead);
                 else run_tile<PT_MATS_SDF, true>(sc, cam, fa, tx, ty, state, out_rgba, sched_seed, stack_mem, ahead);
             } else if (!sc.has_medium) {

@@ -10,7 +10,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ALPHA_VARIANTS, GOLDEN, ROOT, VARIANTS, variant_camera
+from conftest import ALPHA_VARIANTS, GOLDEN, ROOT, VARIANTS, VIEW_VARIANTS, variant_camera
 
 sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
 
@@ -46,6 +46,26 @@ def test_device_code_on_host_matches_reference_golden(prt, oracle, emu, variant,
                             walk_min_lanes=sched[0], sched_seed=sched[1])
     gstate = np.ascontiguousarray(g["state"]).view(oracle.PATH_STATE_DTYPE).reshape(-1)
     _same(oracle, gstate, g["image"], state, img, "%s schedule %s" % (variant, sched))
+
+
+@pytest.mark.parametrize("fixture", list(VIEW_VARIANTS))
+def test_debug_views_on_host_match_reference_golden(prt, oracle, emu, fixture):
+    """the PT_MATS_VIEW kernel variants (prt_config::view_option = VIEW_NORMAL / VIEW_BVH_HIT) under a random schedule; plus an SDF
+    scene against the oracle (a hit that comes out of the hit cache must show what the reference's fresh walk would leave)"""
+    base, view = VIEW_VARIANTS[fixture]
+    g = np.load(os.path.join(GOLDEN, fixture + ".npz"))
+    W, H, frames = int(g["width"]), int(g["height"]), int(g["frames"])
+    scene, cfg, cam, env = _scene(prt, base, W, H)
+    cfg.view_option = view
+    state, img = emu.render(oracle.PATH_STATE_DTYPE, cfg, scene.desc, cam, W, H, prt.seed_pairs(frames), env=env, sched_seed=77)
+    gstate = np.ascontiguousarray(g["state"]).view(oracle.PATH_STATE_DTYPE).reshape(-1)
+    _same(oracle, gstate, g["image"], state, img, fixture)
+    scene, cfg, cam, env = _scene(prt, "cornell_sdf", 29, 19)
+    cfg.view_option = view
+    seeds = prt.seed_pairs(40)
+    ostate, oimg = oracle.Restatement().render(cfg, scene.desc, cam, 29, 19, seeds, env=env, threads=4)
+    state, img = emu.render(oracle.PATH_STATE_DTYPE, cfg, scene.desc, cam, 29, 19, seeds, env=env)
+    _same(oracle, ostate, oimg, state, img, "cornell_sdf view %d" % view)
 
 
 def test_spp_mode_and_batches_on_host(prt, oracle, emu):

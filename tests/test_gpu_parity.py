@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import ALPHA_VARIANTS, GOLDEN, PKG_NAME, VARIANTS, variant_camera
+from conftest import ALPHA_VARIANTS, GOLDEN, PKG_NAME, VARIANTS, VIEW_VARIANTS, variant_camera
 
 pytestmark = pytest.mark.gpu
 
@@ -365,6 +365,54 @@ def test_run_ahead_is_invisible_at_full_size(prt, oracle, monkeypatch):
     _assert_same(oracle, s0, i0, s1, i1, "run-ahead on vs off")
     assert (seg0, smp0, fin0) == (seg1, smp1, fin1) and fin1 == W * H and smp1 == spp * W * H
     assert used1 <= used0 and l1 <= l0           # pixels that ran ahead finish in no more launches
+
+@pytest.mark.parametrize("fixture", list(VIEW_VARIANTS))
+def test_debug_views_match_reference_golden(prt, oracle, fixture):
+    """prt_config::view_option = VIEW_NORMAL / VIEW_BVH_HIT (kernels/main.cl:6-15): fixtures from the reference built with the view
+    switched on; frame batches and an SDF scene against the oracle; the views the reference cannot render are refused"""
+    base, view = VIEW_VARIANTS[fixture]
+    g = np.load(os.path.join(GOLDEN, fixture + ".npz"))
+    W, H, frames = int(g["width"]), int(g["height"]), int(g["frames"])
+    scene_json, phase, use_env = VARIANTS[base]
+    scene = prt.HostScene(scene_json)
+    cfg = scene.config()
+    cfg.phase_function = phase
+    cfg.view_option = view
+    env = prt.make_sky(64, 32) if use_env else None
+    r = prt.Renderer(cfg, device=0)
+    r.upload_scene(scene)
+    if env is not None:
+        r.upload_envmap(env)
+    r.set_camera(variant_camera(prt, base, W, H))
+    r.resize(W, H)
+    seeds = prt.seed_pairs(frames)
+    r.render_frames(seeds[:2 * 40])
+    r.render_frames(seeds[2 * 40:], first_frame=41)
+    gstate = np.ascontiguousarray(g["state"]).view(oracle.PATH_STATE_DTYPE).reshape(-1)
+    _assert_same(oracle, gstate, g["image"], r.read_state(), r.read_framebuffer(), fixture)
+    r.close()
+    scene = prt.HostScene("cornell_sdf.json")
+    cfg = scene.config()
+    cfg.view_option = view
+    cam = variant_camera(prt, "cornell_sdf", 29, 19)
+    seeds = prt.seed_pairs(40)
+    ostate, oimg = oracle.Restatement().render(cfg, scene.desc, cam, 29, 19, seeds, env=env)
+    r = prt.Renderer(cfg, device=0)
+    r.upload_scene(scene)
+    if env is not None:
+        r.upload_envmap(env)
+    r.set_camera(cam)
+    r.resize(29, 19)
+    r.render_frames(seeds)
+    _assert_same(oracle, ostate, oimg, r.read_state(), r.read_framebuffer(), "cornell_sdf view %d" % view)
+    r.close()
+    for bad in (2, 4, 8, 3):                                      # VIEW_STACK_INDEX, VIEW_ALBEDO, VIEW_SPECULAR, a mixture
+        cfg.view_option = bad
+        rb = prt.Renderer(cfg, device=0)
+        with pytest.raises(prt.PrtError, match="view_option"):
+            rb.upload_scene(scene)
+        rb.close()
+
 
 @pytest.mark.parametrize("scatter", ["0", "1"])
 def test_pixel_to_wave_mappings_match_golden(prt, oracle, scatter, monkeypatch):

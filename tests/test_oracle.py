@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import ALPHA_VARIANTS, GOLDEN, VARIANTS, variant_camera
+from conftest import ALPHA_VARIANTS, GOLDEN, VARIANTS, VIEW_VARIANTS, variant_camera
 
 
 def setup(prt, variant, W, H):
@@ -26,6 +26,23 @@ def test_oracle_reproduces_reference_golden(prt, oracle, variant):
     gstate = np.ascontiguousarray(g["state"]).view(oracle.PATH_STATE_DTYPE).reshape(-1)
     assert oracle.state_fields_equal(gstate, state) == []
     assert oracle.images_equal(g["image"], img)
+
+
+@pytest.mark.parametrize("fixture", list(VIEW_VARIANTS))
+def test_oracle_debug_views_reproduce_reference_golden(prt, oracle, fixture):
+    """kernels/main.cl:6-15: VIEW_NORMAL / VIEW_BVH_HIT (the reference built with VIEW_OPTION switched, build_ref.py --view): every
+    frame the accumulator is overwritten with ray.normal as radiance() leaves it, and the image is the accumulator"""
+    base, view = VIEW_VARIANTS[fixture]
+    g = np.load(os.path.join(GOLDEN, fixture + ".npz"))
+    W, H, frames = int(g["width"]), int(g["height"]), int(g["frames"])
+    assert int(g["view"]) == view
+    scene, cfg, cam, env = setup(prt, base, W, H)
+    cfg.view_option = view
+    state, img = oracle.Restatement().render(cfg, scene.desc, cam, W, H, prt.seed_pairs(frames), env=env, threads=4)
+    gstate = np.ascontiguousarray(g["state"]).view(oracle.PATH_STATE_DTYPE).reshape(-1)
+    assert oracle.state_fields_equal(gstate, state) == []
+    assert oracle.images_equal(g["image"], img)
+    assert np.isnan(img).any() and (state["acc"][:, 3] == 1.0).all()      # rays that hit nothing leave normalize(0); alpha is always 1
 
 
 @pytest.mark.parametrize("variant", list(VARIANTS))
