@@ -290,12 +290,15 @@ struct WalkState { unsigned node, sp; float t; TriHit th; unsigned found : 1, do
 
 PT_DEV void walk_begin(const DevScene& sc, const bool ANY_HIT, const Ray& ray, const float tmax, const RayPre& p, WalkState& w,
                        const TravStack& stack) {
-    w.found = false; w.done = false; w.t = tmax;
-    w.th.u = w.th.v = 0.0f; w.th.slot = 0;
+    w.found = false; w.done = false;
+    if (!ANY_HIT) { w.t = tmax; w.th.u = w.th.v = 0.0f; w.th.slot = 0; }   // an any-hit walk leaves (t, u, v) alone: Lane::a lives there (see Lane)
+    float t_any = tmax;
+    TriHit th_any;
+    th_any.u = th_any.v = 0.0f; th_any.slot = 0;
     w.node = 0; w.sp = 0;
     if (sc.root_is_leaf) {                                       // tiny meshes: no tree to walk
         for (unsigned i = sc.root_leaf_first; i < sc.root_leaf_first + sc.root_leaf_count; ++i)
-            if (hit_triangle(sc.tri_geom, i, ray, w.t, w.th)) { w.found = true; if (ANY_HIT) break; }
+            if (hit_triangle(sc.tri_geom, i, ray, ANY_HIT ? t_any : w.t, ANY_HIT ? th_any : w.th)) { w.found = true; if (ANY_HIT) break; }
         w.done = true;
         return;
     }
@@ -303,7 +306,7 @@ PT_DEV void walk_begin(const DevScene& sc, const bool ANY_HIT, const Ray& ray, c
     // uniform): no vector-memory instruction, and the 6 rays in 10 that miss both of the root's children never issue one
     // in this walk.  A root with a leaf child that is hit takes the general step from node 0.
     const PairData d = load_pair(sc.pairs, 0u);
-    const PairTest pt = test_pair(d, p, w.t);
+    const PairTest pt = test_pair(d, p, ANY_HIT ? tmax : w.t);
     const uint4 meta = d.meta;
     if (!((pt.go0 & (meta.y != 0xFFFFFFFFu)) | (pt.go1 & (meta.w != 0xFFFFFFFFu)))) {
         if (pt.go0 != pt.go1) {
@@ -321,8 +324,12 @@ PT_DEV void walk_begin(const DevScene& sc, const bool ANY_HIT, const Ray& ray, c
 }
 
 PT_DEV void walk_step(const DevScene& sc, const bool ANY_HIT, const Ray& ray, const RayPre& p, WalkState& w, const TravStack& stack) {
+    // an any-hit walk never shrinks its limit (it ends at the first hit): ray.t; its hit record is not kept
+    float t_any = ray.t;
+    TriHit th_any;
+    th_any.u = th_any.v = 0.0f; th_any.slot = 0;
     const PairData d = load_pair(sc.pairs, w.node);
-    const PairTest pt = test_pair(d, p, w.t);
+    const PairTest pt = test_pair(d, p, ANY_HIT ? t_any : w.t);
     const uint4 meta = d.meta;
     bool go0 = pt.go0, go1 = pt.go1;
     const bool hit_leaf0 = go0 & (meta.y != 0xFFFFFFFFu), hit_leaf1 = go1 & (meta.w != 0xFFFFFFFFu);
@@ -331,7 +338,7 @@ PT_DEV void walk_step(const DevScene& sc, const bool ANY_HIT, const Ray& ray, co
         const unsigned n0 = hit_leaf0 ? meta.y : 0u, n = n0 + (hit_leaf1 ? meta.w : 0u);
         for (unsigned k = 0; k < n; ++k) {
             const unsigned i = k < n0 ? meta.x + k : meta.z + (k - n0);
-            if (hit_triangle(sc.tri_geom, i, ray, w.t, w.th)) { w.found = true; if (ANY_HIT) { w.done = true; return; } }
+            if (hit_triangle(sc.tri_geom, i, ray, ANY_HIT ? t_any : w.t, ANY_HIT ? th_any : w.th)) { w.found = true; if (ANY_HIT) { w.done = true; return; } }
         }
         if (hit_leaf0) go0 = false;
         if (hit_leaf1) go1 = false;
@@ -1128,7 +1135,6 @@ struct Lane {
     // the scatter event at the segment's vertex (SurfaceScatterEvent, header.cl:208-215) that later phases need
     f3 weight;
     int mesh_id;
-    f3 a;                    // MIS term of the probe ("a" of base.cl:170 / "b" of base.cl:259)
     // Two sets of seven words that are never alive together in one lane share their registers: {wi, n_shade, pdf} goes from
     // lane_front to lane_back, which has read it into an Event before it writes {vis, sh_d, sh_tmax} for phases D and E.
     union {
@@ -1143,7 +1149,13 @@ struct Lane {
     // lane_front on (pathtracing.cl:58-59 assigns them at the end of the segment; nothing reads the old ray in between), the phase
     // weight is `weight`; only the pdf of the phase sample needs a word of its own
     float ps_pdf;
-    WalkState w;             // the walk in flight
+    // the walk in flight -- and, over its (t, u, v), the MIS term of the probe ("a" of base.cl:170 / "b" of base.cl:259): lane_back
+    // writes `a` after lane_closest_done has read the closest-hit walk's result, lane_finish reads it, and the any-hit walk in
+    // between keeps its limit and hit record in locals (walk_begin / walk_step)
+    union {
+        WalkState w;
+        struct { unsigned w_node_, w_sp_; f3 a; };
+    };
     f3 view_n;               // PT_MATS_VIEW variants only: ray.normal as render_kernel finds it after radiance() (main.cl:143-145)
     unsigned f;              // segments completed in this launch
     // Flags and small integers share ONE register (bit-fields of one word): as members of their own each of them costs a
@@ -1166,7 +1178,7 @@ PT_DEV f3 lane_hit_pos(const Lane& L) { return L.origin + L.dir * L.h.t; }
 
 PT_DEV void lane_init(Lane& L) {
     L.kind = K_NONE; L.mesh_id = -1; L.terminate = L.w2_ran = L.sh = false;
-    L.weight = L.a = L.vis = L.sh_d = splat(0.0f);
+    L.weight = L.vis = L.sh_d = splat(0.0f);
     L.sampledLobe = 0u; L.sh_tmax = 0.0f; L.ps_pdf = 1.0f;
     L.rng.s0 = L.rng.s1 = 0u;
     L.h.t = 0.0f; L.h.normal = splat(0.0f); L.h.mesh_id = -1; L.h.didHit = L.h.backside = false; L.h_valid = false;
@@ -1275,7 +1287,7 @@ PT_DEV void lane_front(const DevScene& sc, const DevCamera& cam, const FrameArgs
     L.t = L.h.t;
     L.h_valid = false;
     L.kind = K_NONE; L.terminate = false; L.w2_ran = false; L.sh = false;
-    L.a = splat(0.0f); L.vis = splat(0.0f);
+    L.vis = splat(0.0f);
     const Mat mat = load_mat((L.mesh_id + 1) ? &sc.mats[L.mesh_id + 1] : &sc.mats[sc.n_meshes + 1]);
     f3 emission = splat(0.0f);
     float alpha = 1.0f;
@@ -1381,6 +1393,7 @@ PT_DEV void lane_closest_done(const DevScene& sc, Lane& L) {
 template <unsigned MATS, bool MEDIUM>
 PT_DEV void lane_back(const DevScene& sc, Lane& L) {
     const f3 hit_pos = lane_hit_pos(L);
+    L.a = splat(0.0f);                                                   // (from here on the words of the finished walk's (t, u, v) are `a`)
     f3 sh_o = hit_pos;
     if (L.kind == K_SURFACE_MIS) {
         const Mat mat = load_mat((L.mesh_id + 1) ? &sc.mats[L.mesh_id + 1] : &sc.mats[sc.n_meshes + 1]);

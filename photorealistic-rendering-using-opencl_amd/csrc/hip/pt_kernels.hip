@@ -29,8 +29,9 @@ using namespace dev;
 // waves per SIMD the register allocator must leave room for: 5 (96 VGPRs).  Without packed-float code (build.py:
 // -fno-slp-vectorize), with the lane's flags in one register and its phase-exclusive fields sharing registers (pt_device.h struct
 // Lane) the main loop of the LIGHT|DIFF variant has no spill at 96, and every variant gains over 4 waves (128 VGPRs): +4 ... 9 %.
-// 6 waves (80 VGPRs, 120 B of scratch): -6 % on the teapot, +4 ... 7 % through a tree beyond one XCD's L2, where latency rules
-// (7 the same, 8: -10 %).  PRT_WAVES=4 / 5 / 6 forces one build.
+// 6 waves (80 VGPRs): +3 % for the LIGHT|DIFF variant without a medium (68 B of scratch), +4 ... 7 % through a tree beyond one XCD's
+// L2, where latency rules (7 the same, 8: -10 %); -7 ... -12 % for the generic variants on the teapot, -2 ... 0 % with a medium.
+// PRT_WAVES=4 / 5 / 6 forces one build.
 #ifndef PT_BIG_WAVES
 #define PT_BIG_WAVES 6
 #endif
@@ -377,10 +378,12 @@ template <unsigned MATS, bool MEDIUM>
 static void launch_variant(const DevScene& sc, const DevCamera& cam, const DevState& S, const FrameArgs& fa, float4* fb,
                            hipStream_t stream) {
     static const int forced = [] { const char* e = std::getenv("PRT_WAVES"); return e ? std::atoi(e) : 0; }();   // 4 / 5 / 6: override (tests, experiments)
-    const int waves = forced ? forced : (sc.n_pairs > 65536u ? PT_BIG_WAVES : PT_WAVES);
+    // 6 waves: trees beyond one XCD's L2, and the LIGHT|DIFF variant without a medium (the leanest one: 68 B of scratch at 80 VGPRs)
+    constexpr bool lean = MATS == (PRT_MAT_LIGHT | PRT_MAT_DIFF) && !MEDIUM;
+    const int waves = forced ? forced : ((lean || sc.n_pairs > 65536u) ? PT_BIG_WAVES : PT_WAVES);
 #ifdef PT_DEV_ONE_VARIANT
     (void)waves;
-    launch_variant_w<MATS, MEDIUM, PT_WAVES>(sc, cam, S, fa, fb, stream);
+    launch_variant_w<MATS, MEDIUM, PT_BIG_WAVES>(sc, cam, S, fa, fb, stream);
 #else
     if (waves >= PT_BIG_WAVES) launch_variant_w<MATS, MEDIUM, PT_BIG_WAVES>(sc, cam, S, fa, fb, stream);
     else if (waves <= PT_MIN_WAVES) launch_variant_w<MATS, MEDIUM, PT_MIN_WAVES>(sc, cam, S, fa, fb, stream);
