@@ -56,11 +56,12 @@ struct prt_ctx {
     // and the wave waits for its last lane at the end of each: long launches amortise that (cornell 1080p, MI355X:
     // 128 -> 7.85, 256 -> 8.18, 512 -> 8.33, 1024 -> 8.38, 2048 -> 8.08 G segments/s; 2 x 100 ms launches in flight at 512)
     unsigned frames_per_launch = 512;
-    // walk phases end below this many walking lanes (prt_set_walk_min_lanes; 0 = by variant: 8, with a medium 6).  Round-2 kernel at 4
-    // waves: 1 -> 7.78, 4 -> 8.33, 6 -> 8.37, 8 -> 8.28, 12 -> 7.98; at 5 waves: 4 -> 10.65, 6 -> 11.36, 8 -> 11.45, 12 -> 11.4 (medium: 8 -1 %)
-    uint32_t shadow_min_lanes = 0;                 // 0 = by tree size (frame_args); PRT_SHADOW_MIN_LANES
+    // walk phases end below this many walking lanes (prt_set_walk_min_lanes, PRT_WALK_MIN_LANES; 0 = chosen per launch, pt_kernels.hip
+    // launch_variant_w).  Round-2 kernel at 4 waves: 1 -> 7.78, 4 -> 8.33, 6 -> 8.37, 8 -> 8.28, 12 -> 7.98 G segments/s; at 5 waves:
+    // 4 -> 10.65, 6 -> 11.36, 8 -> 11.45, 12 -> 11.4
+    uint32_t walk_min_lanes = 0;
+    uint32_t shadow_min_lanes = 0;                 // the same for the shadow rays' walk phases (PRT_SHADOW_MIN_LANES; 0 = by tree size)
     uint32_t run_ahead = 1;                        // FrameArgs::run_ahead of prt_render_spp's launches (PRT_RUN_AHEAD=0: off)
-    uint32_t walk_min_lanes = 0;                   // FrameArgs::walk_min_lanes (prt_set_walk_min_lanes, PRT_WALK_MIN_LANES)
     prt_stats stats{};
     std::string err;
     const char* variant = "";
@@ -326,11 +327,10 @@ static FrameArgs frame_args(prt_ctx* c, uint32_t first_frame, uint32_t n, const 
     fa.unfinished = count ? c->d_counters : nullptr;
     fa.unfinished_host = nullptr;
     fa.tile_first = 0; fa.tile_stride = 1; fa.scatter = 0;
-    fa.walk_min_lanes = c->walk_min_lanes ? c->walk_min_lanes : (c->sc.has_medium ? 6u : 8u);
-    // Shadow rays: in a small tree 99 % end at the root and the rest is shallow -- cutting one off costs its pixel a whole
-    // iteration, letting the wave finish them costs a few steps (cornell: 8.40 -> 8.68 G seg/s); through a big mesh they are
-    // as deep as any ray and the bound pays as it does for the closest-hit walks (871 k triangles: 1.44 -> 1.64)
-    fa.shadow_min_lanes = c->shadow_min_lanes ? c->shadow_min_lanes : (c->sc.n_pairs > 65536u ? fa.walk_min_lanes : 1u);
+    // 0 = by launch (pt_kernels.hip launch_variant_w: the scattered-pixel launches and the medium variants 6, the others 8; shadow
+    // phases in lock step in small trees, bounded like the closest-hit phases in big ones)
+    fa.walk_min_lanes = c->walk_min_lanes;
+    fa.shadow_min_lanes = c->shadow_min_lanes;
     return fa;
 }
 

@@ -372,6 +372,12 @@ static void launch_variant_w(const DevScene& sc, const DevCamera& cam, const Dev
     static const int forced_scatter = [] { const char* e = std::getenv("PRT_SCATTER"); return e ? std::atoi(e) : -1; }();
     FrameArgs fb_args = fa;
     fb_args.scatter = forced_scatter >= 0 ? (uint32_t)(forced_scatter != 0) : (uint32_t)(grid <= (sc.n_pairs > 65536u ? 24576u : 6144u));
+    // walk phases end below this many walking lanes (0 = not set by the caller): 8; 6 with a medium (8: -1 %) and for scattered
+    // pixels, whose waves hold more deep walks (512x512 coat: 6 +4 %).  Shadow rays: in a small tree 99 % end at the root and the
+    // rest is shallow -- cutting one off costs its pixel a whole iteration, letting the wave finish them costs a few steps (cornell
+    // +3 %); through a big mesh they are as deep as any ray and the bound pays as it does for the closest-hit walks (+14 %).
+    if (!fb_args.walk_min_lanes) fb_args.walk_min_lanes = (MEDIUM || fb_args.scatter) ? 6u : 8u;
+    if (!fb_args.shadow_min_lanes) fb_args.shadow_min_lanes = sc.n_pairs > 65536u ? fb_args.walk_min_lanes : 1u;
     hipLaunchKernelGGL((render_kernel<MATS, MEDIUM, WAVES>), dim3(grid), dim3(PT_BLOCK), lds, stream, sc, cam, S, fb_args, fb);
 }
 template <unsigned MATS, bool MEDIUM>
