@@ -286,19 +286,21 @@ struct TravRes { bool found; float t; TriHit th; };
 // the fewest vector instructions per step.  The lane machine (lane_kernel) runs a wave's walks for a bounded number of
 // steps; a lane whose ray needs more keeps {node, sp, t, hit} for the wave's next walk phase, the LDS stack column
 // stays the lane's own.  found: (closest) a triangle was accepted, (any) a triangle closer than tmax exists.
-struct WalkState { unsigned node, sp; float t; TriHit th; unsigned found : 1, done : 1; };
+// (u, v, slot: the last accepted triangle, as in TriHit; slot, found and done share a word -- a scene has fewer than 2^30 triangles)
+struct WalkState { unsigned node, sp; float t, u, v; unsigned slot : 30, found : 1, done : 1; };
 
 PT_DEV void walk_begin(const DevScene& sc, const bool ANY_HIT, const Ray& ray, const float tmax, const RayPre& p, WalkState& w,
                        const TravStack& stack) {
     w.found = false; w.done = false;
-    if (!ANY_HIT) { w.t = tmax; w.th.u = w.th.v = 0.0f; w.th.slot = 0; }   // an any-hit walk leaves (t, u, v) alone: Lane::a lives there (see Lane)
+    w.slot = 0;
+    if (!ANY_HIT) { w.t = tmax; w.u = w.v = 0.0f; }              // an any-hit walk leaves (t, u, v) alone: Lane::a lives there (see Lane)
     float t_any = tmax;
-    TriHit th_any;
-    th_any.u = th_any.v = 0.0f; th_any.slot = 0;
+    TriHit th;
+    th.u = th.v = 0.0f; th.slot = 0;
     w.node = 0; w.sp = 0;
     if (sc.root_is_leaf) {                                       // tiny meshes: no tree to walk
         for (unsigned i = sc.root_leaf_first; i < sc.root_leaf_first + sc.root_leaf_count; ++i)
-            if (hit_triangle(sc.tri_geom, i, ray, ANY_HIT ? t_any : w.t, ANY_HIT ? th_any : w.th)) { w.found = true; if (ANY_HIT) break; }
+            if (hit_triangle(sc.tri_geom, i, ray, ANY_HIT ? t_any : w.t, th)) { w.found = true; if (ANY_HIT) break; w.u = th.u; w.v = th.v; w.slot = th.slot; }
         w.done = true;
         return;
     }
@@ -326,8 +328,8 @@ PT_DEV void walk_begin(const DevScene& sc, const bool ANY_HIT, const Ray& ray, c
 PT_DEV void walk_step(const DevScene& sc, const bool ANY_HIT, const Ray& ray, const RayPre& p, WalkState& w, const TravStack& stack) {
     // an any-hit walk never shrinks its limit (it ends at the first hit): ray.t; its hit record is not kept
     float t_any = ray.t;
-    TriHit th_any;
-    th_any.u = th_any.v = 0.0f; th_any.slot = 0;
+    TriHit th;
+    th.u = th.v = 0.0f; th.slot = 0;
     const PairData d = load_pair(sc.pairs, w.node);
     const PairTest pt = test_pair(d, p, ANY_HIT ? t_any : w.t);
     const uint4 meta = d.meta;
@@ -338,7 +340,11 @@ PT_DEV void walk_step(const DevScene& sc, const bool ANY_HIT, const Ray& ray, co
         const unsigned n0 = hit_leaf0 ? meta.y : 0u, n = n0 + (hit_leaf1 ? meta.w : 0u);
         for (unsigned k = 0; k < n; ++k) {
             const unsigned i = k < n0 ? meta.x + k : meta.z + (k - n0);
-            if (hit_triangle(sc.tri_geom, i, ray, ANY_HIT ? t_any : w.t, ANY_HIT ? th_any : w.th)) { w.found = true; if (ANY_HIT) { w.done = true; return; } }
+            if (hit_triangle(sc.tri_geom, i, ray, ANY_HIT ? t_any : w.t, th)) {
+                w.found = true;
+                if (ANY_HIT) { w.done = true; return; }
+                w.u = th.u; w.v = th.v; w.slot = th.slot;
+            }
         }
         if (hit_leaf0) go0 = false;
         if (hit_leaf1) go1 = false;
@@ -1113,7 +1119,7 @@ PT_DEV float power_heuristic(float pdf0, float pdf1) { return (pdf0 * pdf0) / (p
 // The RNG draws happen exactly in the reference's order.
 // (the hit POSITION is not kept: every branch of intersect_scene forms it as origin + dir * t with the final t -- finish_closest --
 // and the ray that was walked stays in the lane's (origin, dir) until the next segment re-aims it: lane_hit_pos forms it again)
-struct Hit { float t; f3 normal; int mesh_id; unsigned didHit : 1, backside : 1; };
+struct Hit { float t; f3 normal; int mesh_id : 24; unsigned didHit : 1, backside : 1; };   // (pack_scene refuses 2^23 meshes and more)
 
 enum { K_NONE = 0, K_SURFACE_MIS = 1, K_SCATTER = 2 };
 enum { ST_READY = 0, ST_WALKC = 1, ST_BACK = 2, ST_WALKS = 3, ST_FINISH = 4 };
@@ -1182,7 +1188,7 @@ PT_DEV void lane_init(Lane& L) {
     L.sampledLobe = 0u; L.sh_tmax = 0.0f; L.ps_pdf = 1.0f;
     L.rng.s0 = L.rng.s1 = 0u;
     L.h.t = 0.0f; L.h.normal = splat(0.0f); L.h.mesh_id = -1; L.h.didHit = L.h.backside = false; L.h_valid = false;
-    L.w.node = L.w.sp = 0u; L.w.t = 0.0f; L.w.th.u = L.w.th.v = 0.0f; L.w.th.slot = 0u; L.w.found = false; L.w.done = true;
+    L.w.node = L.w.sp = 0u; L.w.t = 0.0f; L.w.u = L.w.v = 0.0f; L.w.slot = 0u; L.w.found = false; L.w.done = true;
     L.f = 0u; L.stage = ST_READY;
     L.begun = L.fresh = L.w2 = L.occluded = false;
 }
@@ -1374,7 +1380,7 @@ PT_DEV Ray lane_closest_ray(const Lane& L) {
 template <unsigned MATS, bool MEDIUM>
 PT_DEV void lane_closest_done(const DevScene& sc, Lane& L) {
     TravRes r;
-    r.found = L.w.found; r.t = L.w.t; r.th = L.w.th;
+    r.found = L.w.found; r.t = L.w.t; r.th.u = L.w.u; r.th.v = L.w.v; r.th.slot = L.w.slot;
     Ray wr = lane_closest_ray<MEDIUM>(L);
     int mid;
     const bool hit = finish_closest<(MATS & PT_MATS_SDF) != 0>(sc, wr, r, mid);

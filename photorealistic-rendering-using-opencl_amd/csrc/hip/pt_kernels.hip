@@ -26,12 +26,12 @@ using namespace dev;
 #define PT_WAIT_RATIO 1u    // a walk phase is cut short only while more than this many lanes wait per lane still walking (0: while
                             // any lane waits -- the first form of the rule: 1.3 % slower on cornell, the same on the big mesh)
 #endif
-// waves per SIMD the register allocator must leave room for: 5 (96 VGPRs).  Without packed-float code (build.py:
-// -fno-slp-vectorize), with the lane's flags in one register and its phase-exclusive fields sharing registers (pt_device.h struct
-// Lane) the main loop of the LIGHT|DIFF variant has no spill at 96, and every variant gains over 4 waves (128 VGPRs): +4 ... 9 %.
-// 6 waves (80 VGPRs): +3 % for the LIGHT|DIFF variant without a medium (68 B of scratch), +4 ... 7 % through a tree beyond one XCD's
-// L2, where latency rules (7 the same, 8: -10 %); -7 ... -12 % for the generic variants on the teapot, -2 ... 0 % with a medium.
-// PRT_WAVES=4 / 5 / 6 forces one build.
+// waves per SIMD the register allocator must leave room for: 6 (80 VGPRs).  The history of this number is the history of the lane's
+// registers: 4 (128 VGPRs) while the SLP vectorizer paired floats into 64-bit registers; 5 (96) without it and with the
+// lane's flags as bit-fields of one word; 6 once fields of different phases shared registers, the cached hit dropped its position
+// and the walk state its spare words -- +1 ... 3 % over 5 on every variant (LIGHT|DIFF: 56 B of scratch at 80 VGPRs, none at 96;
+// generic: 88 B; with a medium 76 ... 120 B), +4 ... 7 % through a tree beyond one XCD's L2.  7 waves the same, 8: -10 %.
+// PRT_WAVES=4 / 5 / 6 forces one build (PT_MIN_WAVES / PT_WAVES / PT_BIG_WAVES).
 #ifndef PT_BIG_WAVES
 #define PT_BIG_WAVES 6
 #endif
@@ -354,29 +354,34 @@ __global__ void selftest_fn_kernel(int fn, const float* __restrict__ params, con
 }
 
 // ---- host-side launchers -------------------------------------------------------------------------------
+// tiles (= waves) of this launch, and whether its pixels are scattered over them (render_kernel): on when the launch has few rounds
+// of waves -- up to 6 144 tiles, or 24 576 through a tree beyond one XCD's L2, whose expensive tiles are more expensive (1080p: +14 %,
+// 3840x2160: -4 %)
+static unsigned launch_grid(const DevScene& sc, const FrameArgs& fa, bool& scatter) {
+    const unsigned tiles_x = ((unsigned)fa.width + 7u) / 8u, tiles_y = ((unsigned)fa.rows + 7u) / 8u;
+    const unsigned n_tiles = tiles_x * tiles_y;
+    const unsigned grid = fa.tile_first >= n_tiles ? 0u : (n_tiles - fa.tile_first + fa.tile_stride - 1) / fa.tile_stride;   // tiles of this sub-part
+    static const int forced_scatter = [] { const char* e = std::getenv("PRT_SCATTER"); return e ? std::atoi(e) : -1; }();
+    scatter = forced_scatter >= 0 ? forced_scatter != 0 : grid <= (sc.n_pairs > 65536u ? 24576u : 6144u);
+    return grid;
+}
 template <unsigned MATS, bool MEDIUM, int WAVES>
 static void launch_variant_w(const DevScene& sc, const DevCamera& cam, const DevState& S, const FrameArgs& fa, float4* fb,
-                             hipStream_t stream) {
-    const unsigned tiles_x = ((unsigned)fa.width + 7u) / 8u, tiles_y = ((unsigned)fa.rows + 7u) / 8u;
+                             hipStream_t stream, unsigned grid, bool scatter) {
     const size_t lds = (size_t)sc.stack_levels * PT_BLOCK * sizeof(unsigned);
     static size_t lds_attr = 0;                                  // per template instance
-    if (lds > 65536u && lds > lds_attr) {   // only a 4-wave build with a tree that fills the reference's 64-entry stack to the brim
+    if (lds > 65536u && lds > lds_attr) {   // only a tree that fills the reference's 64-entry stack to the brim
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<MATS, MEDIUM, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         lds_attr = lds;
     }
-    const unsigned n_tiles = tiles_x * tiles_y;
-    if (fa.tile_first >= n_tiles) return;
-    const unsigned grid = (n_tiles - fa.tile_first + fa.tile_stride - 1) / fa.tile_stride;      // tiles of this sub-part
-    // pixels scattered over the waves (render_kernel) when the launch has few rounds of waves: up to 6 144 tiles, or 24 576
-    // through a tree beyond one XCD's L2, whose expensive tiles are more expensive (1080p: +14 %, 3840x2160: -4 %)
-    static const int forced_scatter = [] { const char* e = std::getenv("PRT_SCATTER"); return e ? std::atoi(e) : -1; }();
+    if (!grid) return;
     FrameArgs fb_args = fa;
-    fb_args.scatter = forced_scatter >= 0 ? (uint32_t)(forced_scatter != 0) : (uint32_t)(grid <= (sc.n_pairs > 65536u ? 24576u : 6144u));
+    fb_args.scatter = scatter ? 1u : 0u;
     // walk phases end below this many walking lanes (0 = not set by the caller): 8; 6 with a medium (8: -1 %) and for scattered
     // pixels, whose waves hold more deep walks (512x512 coat: 6 +4 %).  Shadow rays: in a small tree 99 % end at the root and the
     // rest is shallow -- cutting one off costs its pixel a whole iteration, letting the wave finish them costs a few steps (cornell
     // +3 %); through a big mesh they are as deep as any ray and the bound pays as it does for the closest-hit walks (+14 %).
-    if (!fb_args.walk_min_lanes) fb_args.walk_min_lanes = (MEDIUM || fb_args.scatter) ? 6u : 8u;
+    if (!fb_args.walk_min_lanes) fb_args.walk_min_lanes = (MEDIUM || scatter) ? 6u : 8u;
     if (!fb_args.shadow_min_lanes) fb_args.shadow_min_lanes = sc.n_pairs > 65536u ? fb_args.walk_min_lanes : 1u;
     hipLaunchKernelGGL((render_kernel<MATS, MEDIUM, WAVES>), dim3(grid), dim3(PT_BLOCK), lds, stream, sc, cam, S, fb_args, fb);
 }
@@ -384,16 +389,18 @@ template <unsigned MATS, bool MEDIUM>
 static void launch_variant(const DevScene& sc, const DevCamera& cam, const DevState& S, const FrameArgs& fa, float4* fb,
                            hipStream_t stream) {
     static const int forced = [] { const char* e = std::getenv("PRT_WAVES"); return e ? std::atoi(e) : 0; }();   // 4 / 5 / 6: override (tests, experiments)
-    // 6 waves: trees beyond one XCD's L2, and the LIGHT|DIFF variant without a medium (the leanest one: 68 B of scratch at 80 VGPRs)
-    constexpr bool lean = MATS == (PRT_MAT_LIGHT | PRT_MAT_DIFF) && !MEDIUM;
-    const int waves = forced ? forced : ((lean || sc.n_pairs > 65536u) ? PT_BIG_WAVES : PT_WAVES);
+    bool scatter;
+    const unsigned grid = launch_grid(sc, fa, scatter);
+    // 6 waves per SIMD; 5 where a launch of a small tree is one or two rounds of waves (scattered pixels): every wave then runs at its
+    // own latency and the spills of the 80-register build cost more than the sixth wave hides (512x512 coat: 5 +5 %)
+    const int waves = forced ? forced : ((scatter && sc.n_pairs <= 65536u) ? PT_WAVES : PT_BIG_WAVES);
 #ifdef PT_DEV_ONE_VARIANT
     (void)waves;
-    launch_variant_w<MATS, MEDIUM, PT_BIG_WAVES>(sc, cam, S, fa, fb, stream);
+    launch_variant_w<MATS, MEDIUM, PT_BIG_WAVES>(sc, cam, S, fa, fb, stream, grid, scatter);
 #else
-    if (waves >= PT_BIG_WAVES) launch_variant_w<MATS, MEDIUM, PT_BIG_WAVES>(sc, cam, S, fa, fb, stream);
-    else if (waves <= PT_MIN_WAVES) launch_variant_w<MATS, MEDIUM, PT_MIN_WAVES>(sc, cam, S, fa, fb, stream);
-    else launch_variant_w<MATS, MEDIUM, PT_WAVES>(sc, cam, S, fa, fb, stream);
+    if (waves >= PT_BIG_WAVES) launch_variant_w<MATS, MEDIUM, PT_BIG_WAVES>(sc, cam, S, fa, fb, stream, grid, scatter);
+    else if (waves <= PT_MIN_WAVES) launch_variant_w<MATS, MEDIUM, PT_MIN_WAVES>(sc, cam, S, fa, fb, stream, grid, scatter);
+    else launch_variant_w<MATS, MEDIUM, PT_WAVES>(sc, cam, S, fa, fb, stream, grid, scatter);
 #endif
 }
 
@@ -427,12 +434,14 @@ const char* launch_render(const DevScene& sc, const DevCamera& cam, const DevSta
 #else
     if (sc.view) {                        // the debug views: generic material set, the default wave count only
         constexpr unsigned V = PT_MATS_VIEW, VS = PT_MATS_VIEW | PT_MATS_SDF;
+        bool vscatter;
+        const unsigned vgrid = launch_grid(sc, fa, vscatter);
         if (sc.n_sdfs) {
-            if (!sc.has_medium) launch_variant_w<VS, false, PT_WAVES>(sc, cam, S, fa, fb, stream);
-            else launch_variant_w<VS, true, PT_WAVES>(sc, cam, S, fa, fb, stream);
+            if (!sc.has_medium) launch_variant_w<VS, false, PT_BIG_WAVES>(sc, cam, S, fa, fb, stream, vgrid, vscatter);
+            else launch_variant_w<VS, true, PT_BIG_WAVES>(sc, cam, S, fa, fb, stream, vgrid, vscatter);
         } else {
-            if (!sc.has_medium) launch_variant_w<V, false, PT_WAVES>(sc, cam, S, fa, fb, stream);
-            else launch_variant_w<V, true, PT_WAVES>(sc, cam, S, fa, fb, stream);
+            if (!sc.has_medium) launch_variant_w<V, false, PT_BIG_WAVES>(sc, cam, S, fa, fb, stream, vgrid, vscatter);
+            else launch_variant_w<V, true, PT_BIG_WAVES>(sc, cam, S, fa, fb, stream, vgrid, vscatter);
         }
         return "render_kernel<generic,view>";
     }

@@ -29,7 +29,9 @@ int pack_scene(const prt_config& cfg, const prt_scene_desc* s, PackedScene& out,
     if (n_sph + n_sdf + n_quad != n_mesh) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: object_count does not add up");
     if (n_sdf && !(cfg.geom_flags & PRT_GEOM_SDF)) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: SDF meshes but the config has no H_SDF");
     if (n_mesh && !s->meshes) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: meshes is null");
+    if (n_mesh >= (1u << 23)) return fail(c, PRT_ERR_UNSUPPORTED, "prt_upload_scene: 2^23 primitives or more (a hit record keeps the mesh index in 24 bits)");
     const uint32_t T = s->triangle_count, N = s->bvh_node_count;
+    if (T >= (1u << 30)) return fail(c, PRT_ERR_UNSUPPORTED, "prt_upload_scene: 2^30 triangles or more");
     if (T && (!s->vertices || !s->normals || !s->primitive_indices || !s->bvh_nodes || !N))
         return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: triangle buffers incomplete");
 

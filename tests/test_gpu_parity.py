@@ -442,11 +442,10 @@ def test_pixel_to_wave_mappings_match_golden(prt, oracle, scatter, monkeypatch):
     r.close()
 
 
-@pytest.mark.parametrize("waves", ["4", "6"])
+@pytest.mark.parametrize("waves", ["4", "5"])
 @pytest.mark.parametrize("variant", ["cornell_diffuse", "cornell_media_hg", "cornell_sdf", "cornell_mixed"])
 def test_other_wave_count_builds_match_golden(prt, oracle, variant, waves, monkeypatch):
-    """every kernel variant is built for 4, 5 and 6 waves per SIMD (128 / 96 / 80 registers): 5 is the default, big trees run
-    the 6-wave build; forced here on the small scenes"""
+    """every kernel variant is built for 4, 5 and 6 waves per SIMD (128 / 96 / 80 registers): 6 is the default, the others forced here"""
     monkeypatch.setenv("PRT_WAVES", waves)
     g = np.load(os.path.join(GOLDEN, variant + ".npz"))
     W, H, frames = int(g["width"]), int(g["height"]), int(g["frames"])
