@@ -61,7 +61,7 @@ launches_per_step = line["roofline"]["launches"] / line["steps"]
 traffic = {
     "workload": "1920x1080_1024spp_cornell_diffuse.json",
     "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --output-format csv -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0   (tools/profile_round.sh)",
-    "kernel": "prt::render_kernel<3u,false,5> (lane machine)",
+    "kernel": "prt::render_kernel<3u,false,6> (lane machine)",
     "dispatches": fetch["dispatches"],
     "FETCH_SIZE_bytes_per_launch_raw": round(fetch["sum"] * 1024.0 / fetch["dispatches"]),
     "WRITE_SIZE_bytes_per_launch": round(write["sum"] * 1024.0 / write["dispatches"]),
@@ -79,7 +79,7 @@ with open(os.path.join(dst, tag + "traffic.json"), "w") as f:
 c = sums(["pmc_set%d.json" % k for k in range(1, 6)])
 cornell = {
     "workload": "cornell_diffuse.json 1920x1080, 128 spp (counter passes serialise the two streams: one launch at a time)",
-    "kernel": "render_kernel<LIGHT|DIFF, 5 waves> (lane machine, walk_min_lanes 6 / shadow phases in lock step, 512 frames per launch)",
+    "kernel": "render_kernel<LIGHT|DIFF, 6 waves> (lane machine, walk_min_lanes 8 / shadow phases in lock step, 512 frames per launch)",
     "counters": c,
     "derived": derived(c, segments_of("pmc_set1.log")),
 }
