@@ -165,7 +165,8 @@ int prt_render_spp(prt_ctx* ctx, uint32_t spp, uint32_t max_frames, const int32_
 /* Scheduling knob of the render kernel (no counterpart in the reference; results do not depend on it, tests check
  * that): a wave ends a BVH-walk phase once fewer than `lanes` of its 64 lanes are still walking (and fewer than wait for the
  * phase to end); the lanes cut off resume in the wave's next phase.  1 = every walk runs to its end (lock step).
- * Default: 8 (6 with a global medium, and for launches with scattered pixels) for the closest-hit phases (PRT_WALK_MIN_LANES); for the shadow rays' any-hit
+ * Default: 8 (6 with a global medium and for launches with scattered pixels, 12 through big trees) for the closest-hit phases
+ * (PRT_WALK_MIN_LANES); for the shadow rays' any-hit
  * phases 1 in small trees and the same as above in big ones (PRT_SHADOW_MIN_LANES).  A call of this function sets both. */
 int prt_set_walk_min_lanes(prt_ctx* ctx, uint32_t lanes);
 
