@@ -31,7 +31,7 @@ struct prt_ctx {
     bool timing_pending = false;
     // scene
     DevScene sc{};
-    void* d_pairs = nullptr; void* d_tri_geom = nullptr; void* d_tri_nrm = nullptr;
+    void* d_pairs = nullptr; void* d_recs = nullptr; void* d_leaf_ext = nullptr; void* d_tri_geom = nullptr; void* d_tri_nrm = nullptr;
     void* d_spheres = nullptr; void* d_quads = nullptr; void* d_sdfs = nullptr; void* d_mats = nullptr; void* d_env = nullptr;
     bool have_scene = false, have_cam = false, have_size = false;
     DevCamera cam{};
@@ -139,7 +139,7 @@ static void free_frame(prt_ctx* c) {
     p = c->fb; free_dev(p); c->fb = nullptr;
 }
 static void free_scene(prt_ctx* c) {
-    free_dev(c->d_pairs); free_dev(c->d_tri_geom); free_dev(c->d_tri_nrm);
+    free_dev(c->d_pairs); free_dev(c->d_recs); free_dev(c->d_leaf_ext); free_dev(c->d_tri_geom); free_dev(c->d_tri_nrm);
     free_dev(c->d_spheres); free_dev(c->d_quads); free_dev(c->d_sdfs); free_dev(c->d_mats);
 }
 
@@ -193,12 +193,15 @@ extern "C" int prt_upload_scene(prt_ctx* c, const prt_scene_desc* s) {
     const float* env = c->sc.env; const int env_w = c->sc.env_w, env_h = c->sc.env_h;    // the environment map survives scene uploads
     c->sc = DevScene{};
     c->sc.env = env; c->sc.env_w = env_w; c->sc.env_h = env_h;
-    if ((rc = upload(c, c->d_pairs, ps.pairs)) || (rc = upload(c, c->d_tri_geom, ps.tg)) || (rc = upload(c, c->d_tri_nrm, ps.tn)) ||
+    if ((rc = upload(c, c->d_pairs, ps.pairs)) || (rc = upload(c, c->d_recs, ps.recs)) || (rc = upload(c, c->d_leaf_ext, ps.leaf_ext)) ||
+        (rc = upload(c, c->d_tri_geom, ps.tg)) || (rc = upload(c, c->d_tri_nrm, ps.tn)) ||
         (rc = upload(c, c->d_spheres, ps.spheres)) || (rc = upload(c, c->d_quads, ps.quads)) || (rc = upload(c, c->d_sdfs, ps.sdfs)) ||
         (rc = upload(c, c->d_mats, ps.mats)))
         return rc;
     DevScene sc = ps.sc;
     sc.pairs = static_cast<const NodePair*>(c->d_pairs);
+    sc.recs = static_cast<const NodeRec*>(c->d_recs);
+    sc.leaf_ext = static_cast<const uint2*>(c->d_leaf_ext);
     sc.tri_geom = static_cast<const TriGeom*>(c->d_tri_geom);
     sc.tri_nrm = static_cast<const TriNrm*>(c->d_tri_nrm);
     sc.spheres = static_cast<const DevSphere*>(c->d_spheres);

@@ -419,6 +419,12 @@ void dump_phase_clocks() {
         else fprintf(stderr, "phase clocks: %-16s %5.1f %%\n", names[k], 100.0 * (double)h[k] / tot);
     if (h[10]) fprintf(stderr, "phase clocks: waves %llu, iterations per wave mean %.0f max %llu, cycles per wave mean %.0f max %llu\n", h[10],
                        (double)h[6] / (double)h[10], h[8], tot / (double)h[10], h[9]);
+    unsigned long long ws[8] = {0};
+    if (hipMemcpyFromSymbol(ws, HIP_SYMBOL(dev::g_walk_stats), sizeof(ws)) == hipSuccess) {
+        const char* wn[4] = {"closest box steps", "closest triangle iterations", "any-hit box steps", "any-hit triangle iterations"};
+        for (int k = 0; k < 4; ++k)
+            fprintf(stderr, "phase clocks: %-28s %llu wave-level, %.1f lanes each\n", wn[k], ws[2 * k], ws[2 * k] ? (double)ws[2 * k + 1] / (double)ws[2 * k] : 0.0);
+    }
     if (h[6]) fprintf(stderr, "phase clocks: lanes that have done their frames (or their samples) and wait for the wave: %.1f %% of the lane-iterations\n",
                       100.0 * (double)h[11] / (64.0 * (double)h[6]));
 }

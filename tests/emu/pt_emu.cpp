@@ -157,7 +157,7 @@ extern "C" int emu_render(const prt_config* cfg, const prt_scene_desc* desc, con
         return rc;
     }
     DevScene sc = ps.sc;
-    sc.pairs = ps.pairs.data(); sc.tri_geom = ps.tg.data(); sc.tri_nrm = ps.tn.data();
+    sc.pairs = ps.pairs.data(); sc.recs = ps.recs.data(); sc.leaf_ext = ps.leaf_ext.data(); sc.tri_geom = ps.tg.data(); sc.tri_nrm = ps.tn.data();
     sc.spheres = ps.spheres.data(); sc.quads = ps.quads.data(); sc.sdfs = ps.sdfs.data(); sc.mats = ps.mats.data();
     static const float black[3] = {0.f, 0.f, 0.f};
     sc.env = env_rgb ? env_rgb : black; sc.env_w = env_rgb ? env_w : 1; sc.env_h = env_rgb ? env_h : 1;
