@@ -31,7 +31,7 @@ struct prt_ctx {
     bool timing_pending = false;
     // scene
     DevScene sc{};
-    void* d_pairs = nullptr; void* d_recs = nullptr; void* d_leaf_ext = nullptr; void* d_tri_geom = nullptr; void* d_tri_nrm = nullptr;
+    void* d_pairs = nullptr; void* d_tri_geom = nullptr; void* d_tri_nrm = nullptr;
     void* d_spheres = nullptr; void* d_quads = nullptr; void* d_sdfs = nullptr; void* d_mats = nullptr; void* d_env = nullptr;
     bool have_scene = false, have_cam = false, have_size = false;
     DevCamera cam{};
@@ -61,6 +61,8 @@ struct prt_ctx {
     // 4 -> 10.65, 6 -> 11.36, 8 -> 11.45, 12 -> 11.4
     uint32_t walk_min_lanes = 0;
     uint32_t shadow_min_lanes = 0;                 // the same for the shadow rays' walk phases (PRT_SHADOW_MIN_LANES; 0 = by tree size)
+    // the pending triangle tests of a walk phase run once this many sixteenths of its walking lanes have one (PRT_TRI_Q; render_kernel)
+    uint32_t tri_sixteenths = 4;
     uint32_t run_ahead = 1;                        // FrameArgs::run_ahead of prt_render_spp's launches (PRT_RUN_AHEAD=0: off)
     prt_stats stats{};
     std::string err;
@@ -124,6 +126,7 @@ extern "C" int prt_create(int device, const prt_config* cfg, prt_ctx** out) {
     if (const char* ev = std::getenv("PRT_FRAMES_PER_LAUNCH")) { const int k = std::atoi(ev); if (k >= 1) c->frames_per_launch = (unsigned)k; }
     if (const char* ev = std::getenv("PRT_RUN_AHEAD")) c->run_ahead = std::atoi(ev) != 0 ? 1u : 0u;
     if (const char* ev = std::getenv("PRT_WALK_MIN_LANES")) { const int k = std::atoi(ev); if (k >= 1 && k <= 64) c->walk_min_lanes = (uint32_t)k; }
+    if (const char* ev = std::getenv("PRT_TRI_Q")) { const int k = std::atoi(ev); if (k >= 0 && k <= 16) c->tri_sixteenths = (uint32_t)k; }
     if (const char* ev = std::getenv("PRT_SHADOW_MIN_LANES")) { const int k = std::atoi(ev); if (k >= 1 && k <= 64) c->shadow_min_lanes = (uint32_t)k; }
     *out = c;
     return PRT_OK;
@@ -139,7 +142,7 @@ static void free_frame(prt_ctx* c) {
     p = c->fb; free_dev(p); c->fb = nullptr;
 }
 static void free_scene(prt_ctx* c) {
-    free_dev(c->d_pairs); free_dev(c->d_recs); free_dev(c->d_leaf_ext); free_dev(c->d_tri_geom); free_dev(c->d_tri_nrm);
+    free_dev(c->d_pairs); free_dev(c->d_tri_geom); free_dev(c->d_tri_nrm);
     free_dev(c->d_spheres); free_dev(c->d_quads); free_dev(c->d_sdfs); free_dev(c->d_mats);
 }
 
@@ -193,15 +196,12 @@ extern "C" int prt_upload_scene(prt_ctx* c, const prt_scene_desc* s) {
     const float* env = c->sc.env; const int env_w = c->sc.env_w, env_h = c->sc.env_h;    // the environment map survives scene uploads
     c->sc = DevScene{};
     c->sc.env = env; c->sc.env_w = env_w; c->sc.env_h = env_h;
-    if ((rc = upload(c, c->d_pairs, ps.pairs)) || (rc = upload(c, c->d_recs, ps.recs)) || (rc = upload(c, c->d_leaf_ext, ps.leaf_ext)) ||
-        (rc = upload(c, c->d_tri_geom, ps.tg)) || (rc = upload(c, c->d_tri_nrm, ps.tn)) ||
+    if ((rc = upload(c, c->d_pairs, ps.pairs)) || (rc = upload(c, c->d_tri_geom, ps.tg)) || (rc = upload(c, c->d_tri_nrm, ps.tn)) ||
         (rc = upload(c, c->d_spheres, ps.spheres)) || (rc = upload(c, c->d_quads, ps.quads)) || (rc = upload(c, c->d_sdfs, ps.sdfs)) ||
         (rc = upload(c, c->d_mats, ps.mats)))
         return rc;
     DevScene sc = ps.sc;
     sc.pairs = static_cast<const NodePair*>(c->d_pairs);
-    sc.recs = static_cast<const NodeRec*>(c->d_recs);
-    sc.leaf_ext = static_cast<const uint2*>(c->d_leaf_ext);
     sc.tri_geom = static_cast<const TriGeom*>(c->d_tri_geom);
     sc.tri_nrm = static_cast<const TriNrm*>(c->d_tri_nrm);
     sc.spheres = static_cast<const DevSphere*>(c->d_spheres);
@@ -334,6 +334,7 @@ static FrameArgs frame_args(prt_ctx* c, uint32_t first_frame, uint32_t n, const 
     // phases in lock step in small trees, bounded like the closest-hit phases in big ones)
     fa.walk_min_lanes = c->walk_min_lanes;
     fa.shadow_min_lanes = c->shadow_min_lanes;
+    fa.tri_sixteenths = c->tri_sixteenths;
     return fa;
 }
 

@@ -22,9 +22,6 @@
 namespace prt {
 namespace dev {
 
-#ifndef PT_REC
-#define PT_REC 0            // walks read the two-level NodeRec records (0: the NodePair array; 2: a step into an inlined child goes on in the same call)
-#endif
 #define PT_EPS 1e-5f
 #define PT_INF 2e1f
 #define PT_PI 3.1415926535897932384626433832795f
@@ -221,9 +218,7 @@ struct TriHit { float u, v; unsigned slot; };      // w = 1.0f - u - v is formed
 
 // triangle.cl:4-43; `best_t` is ray->t.  The smooth normal (triangle.cl:30-34) is deferred to the
 // end of the traversal: it only depends on (u, v, w, slot) of the last accepted hit.
-PT_DEV bool hit_triangle(const TriGeom* __restrict__ tg, unsigned slot, const Ray& ray, float& best_t, TriHit& th) {
-    const float4* q = reinterpret_cast<const float4*>(tg + slot);
-    const float4 a = q[0], b = q[1], c4 = q[2];
+PT_DEV bool hit_triangle_data(const float4 a, const float4 b, const float4 c4, const unsigned slot, const Ray& ray, float& best_t, TriHit& th) {
     const f3 p0 = F3(a.x, a.y, a.z), e1 = F3(a.w, b.x, b.y), e2 = F3(b.z, b.w, c4.x), n = F3(c4.y, c4.z, c4.w);
     f3 c = p0 - ray.origin;
     f3 r = cross(ray.dir, c);
@@ -240,6 +235,11 @@ PT_DEV bool hit_triangle(const TriGeom* __restrict__ tg, unsigned slot, const Ra
         }
     }
     return false;
+}
+PT_DEV bool hit_triangle(const TriGeom* __restrict__ tg, unsigned slot, const Ray& ray, float& best_t, TriHit& th) {
+    const float4* q = reinterpret_cast<const float4*>(tg + slot);
+    const float4 a = q[0], b = q[1], c4 = q[2];
+    return hit_triangle_data(a, b, c4, slot, ray, best_t, th);
 }
 
 // Traversal stack in LDS, [level][thread] (conflict-free), `levels` chosen per scene from the tree
@@ -281,28 +281,40 @@ PT_DEV PairTest test_pair(const PairData& d, const RayPre& p, float best_t) {
 
 struct TravRes { bool found; float t; TriHit th; };
 
-#if defined(PT_PHASE_CLOCKS) && !defined(PT_EMU)    // development builds: wave-level counts of the walk (tools/phase_clocks.sh)
-__device__ unsigned long long g_walk_stats[8];
+#if defined(PT_WALK_STATS) && !defined(PT_EMU)    // development builds (with -DPT_PHASE_CLOCKS): wave-level counts of the walk (tools/phase_clocks.sh)
+__device__ unsigned long long g_walk_stats[16];
 #define PT_WSTAT(k) do { const unsigned long long m_ = __ballot(1); if ((threadIdx.x & 63u) == (unsigned)__builtin_ctzll(m_)) { atomicAdd(&g_walk_stats[2 * (k)], 1ull); atomicAdd(&g_walk_stats[2 * (k) + 1], (unsigned long long)__popcll(m_)); } } while (0)
 #else
 #define PT_WSTAT(k) do { } while (0)
 #endif
-// bvh.cl:132-206 (closest hit) / :43-114 (any hit), as a RESUMABLE walk: walk_begin = set-up + the step at the root,
-// walk_step = one step of bvh.cl:144-196 (closest hit) / :54-104 (any hit).  Same visiting order as the reference:
-// both children's boxes are tested against the CURRENT best t before either leaf is tested; leaf children are tested
-// immediately, left first; of two inner children the nearer (by entry distance, ties -> left) is followed and the
-// other pushed.  Real branches (scalar mask work, free next to the vector pipe) rather than selects: the shape with
-// the fewest vector instructions per step.  The lane machine (lane_kernel) runs a wave's walks for a bounded number of
-// steps; a lane whose ray needs more keeps {node, sp, t, hit} for the wave's next walk phase, the LDS stack column
-// stays the lane's own.  found: (closest) a triangle was accepted, (any) a triangle closer than tmax exists.
-// (u, v, slot: the last accepted triangle, as in TriHit; slot, found and done share a word -- a scene has fewer than 2^30 triangles)
-struct WalkState { unsigned node, sp; float t, u, v; unsigned slot : 30, found : 1, done : 1; };
+// bvh.cl:132-206 (closest hit) / :43-114 (any hit), as a RESUMABLE walk with DEFERRED LEAVES: walk_begin = set-up + the step at
+// the root, walk_box = the box tests and the descent of one step of bvh.cl:144-196 (closest hit) / :54-104 (any hit), walk_tri =
+// ONE triangle of the leaves that step found.  Same visiting order as the reference: both children's boxes are tested against
+// the CURRENT best t before either leaf is tested; leaf children are tested at once, left first -- a lane whose step hit a leaf
+// takes no further box test before every triangle of that leaf (of both, when both children are leaves that were hit) has been
+// tested; of two inner children the nearer (by entry distance, ties -> left) is followed and the other pushed.  What the split
+// buys: the triangle test is the code a wave executes worst -- in the one-call step every walk step of a wave ran the triangle
+// loop for the one or two lanes that had found a leaf (1.7 lanes of 64 per iteration through an 871 k-triangle mesh, two
+// iterations per box step) -- and as a call of its own the kernel runs it when enough lanes have a triangle to test
+// (render_kernel).  The pending triangles are ONE run of slots: pack_scene lays the triangles of a pair's two leaf children out
+// next to each other.  Real branches (scalar mask work, free next to the vector pipe) rather than selects.  The lane machine runs
+// a wave's walks for a bounded number of steps; a lane whose ray needs more keeps {node, sp, t, hit, pending run} for the wave's
+// next walk phase, the LDS stack column stays the lane's own.  found: (closest) a triangle was accepted, (any) a triangle closer
+// than tmax exists.  (u, v, slot: the last accepted triangle, as in TriHit; slot and three flags share a word -- pack_scene
+// refuses 2^29 triangle slots and more; `last`: the stack was empty when the step ended: the walk is over once the run is tested)
+struct WalkState {
+    unsigned node;
+    unsigned sp : 7, pend_count : 25;       // entries on the stack (at most 64); triangles of the step's leaves still to test
+    float t, u, v;
+    unsigned slot : 29, found : 1, done : 1, last : 1;
+    unsigned pend_first;                    // first slot of the pending run
+};
 
-#if !PT_REC
 PT_DEV void walk_begin(const DevScene& sc, const bool ANY_HIT, const Ray& ray, const float tmax, const RayPre& p, WalkState& w,
                        const TravStack& stack) {
-    w.found = false; w.done = false;
+    w.found = false; w.done = false; w.last = false;
     w.slot = 0;
+    w.pend_count = 0; w.pend_first = 0;
     if (!ANY_HIT) { w.t = tmax; w.u = w.v = 0.0f; }              // an any-hit walk leaves (t, u, v) alone: Lane::a lives there (see Lane)
     float t_any = tmax;
     TriHit th;
@@ -335,32 +347,23 @@ PT_DEV void walk_begin(const DevScene& sc, const bool ANY_HIT, const Ray& ray, c
     }
 }
 
-PT_DEV void walk_step(const DevScene& sc, const bool ANY_HIT, const Ray& ray, const RayPre& p, WalkState& w, const TravStack& stack) {
-    // an any-hit walk never shrinks its limit (it ends at the first hit): ray.t; its hit record is not kept
-    float t_any = ray.t;
-    TriHit th;
-    th.u = th.v = 0.0f; th.slot = 0;
+// the box half of a step (the lane has no triangle pending), on the pair `d` = pairs[w.node]
+PT_DEV void walk_box_data(const PairData& d, const bool ANY_HIT, const Ray& ray, const RayPre& p, WalkState& w, const TravStack& stack) {
     PT_WSTAT(ANY_HIT ? 2 : 0);
-    const PairData d = load_pair(sc.pairs, w.node);
-    const PairTest pt = test_pair(d, p, ANY_HIT ? t_any : w.t);
+    // an any-hit walk never shrinks its limit (it ends at the first hit): ray.t
+    const PairTest pt = test_pair(d, p, ANY_HIT ? ray.t : w.t);
     const uint4 meta = d.meta;
     bool go0 = pt.go0, go1 = pt.go1;
     const bool hit_leaf0 = go0 & (meta.y != 0xFFFFFFFFu), hit_leaf1 = go1 & (meta.w != 0xFFFFFFFFu);
+    unsigned pend = 0u;
     if (hit_leaf0 | hit_leaf1) {
-        // one loop over the triangles of both leaf children, the left one's first (the order the reference tests them in)
-        const unsigned n0 = hit_leaf0 ? meta.y : 0u, n = n0 + (hit_leaf1 ? meta.w : 0u);
-        for (unsigned k = 0; k < n; ++k) {
-            PT_WSTAT(ANY_HIT ? 3 : 1);
-            const unsigned i = k < n0 ? meta.x + k : meta.z + (k - n0);
-            if (hit_triangle(sc.tri_geom, i, ray, ANY_HIT ? t_any : w.t, th)) {
-                w.found = true;
-                if (ANY_HIT) { w.done = true; return; }
-                w.u = th.u; w.v = th.v; w.slot = th.slot;
-            }
-        }
+        // the triangles of both leaf children are one run of slots, the left child's first (the order the reference tests them in)
+        w.pend_first = hit_leaf0 ? meta.x : meta.z;
+        pend = (hit_leaf0 ? meta.y : 0u) + (hit_leaf1 ? meta.w : 0u);
         if (hit_leaf0) go0 = false;
         if (hit_leaf1) go1 = false;
     }
+    w.pend_count = pend;
     if (go0 != go1) {
         w.node = go0 ? meta.x : meta.z;
     } else if (go0) {
@@ -369,141 +372,54 @@ PT_DEV void walk_step(const DevScene& sc, const bool ANY_HIT, const Ray& ray, co
         stack.lds[w.sp * stack.stride] = farc;
         ++w.sp;
         w.node = nearc;
+    } else if (w.sp == 0u) {
+        if (pend) w.last = true; else w.done = true;             // nothing left but (maybe) this step's triangles
     } else {
-        if (w.sp == 0u) { w.done = true; return; }
-        --w.sp;
+        --w.sp;                                                  // (the triangle tests touch neither the stack nor the node)
         w.node = stack.lds[w.sp * stack.stride];
     }
 }
-#else   // PT_REC: the same walk over the two-level records of pt_layout.h (NodeRec)
-// One VISIT = the reference's step at one pair (bvh.cl:144-196 / :54-104): the pair's two boxes come from the record's
-// first 48 bytes (node word = record * 4) or, for a child inlined into the record (node word = record * 4 + 1 + k), from
-// that child's own box + its 6 stored planes + 6 selector bits -- the same 12 floats, bit for bit.
-struct RecHead { float4 b0, b1, b2; uint4 m; };
-PT_DEV RecHead load_rec_head(const float4* __restrict__ q) {
-    RecHead h;
-    h.b0 = q[0]; h.b1 = q[1]; h.b2 = q[2];
-    h.m = *reinterpret_cast<const uint4*>(q + 3);
-    return h;
-}
-PT_DEV PairData rec_visit_data(const RecHead& h, const float4* __restrict__ q, const unsigned sub) {
-    PairData d;
-    if (sub == 0u) { d.b0 = h.b0; d.b1 = h.b1; d.b2 = h.b2; d.meta = h.m; return d; }
-    const unsigned k = sub - 1u;
-    const float4 n0 = q[4u + 2u * k], n1 = q[5u + 2u * k];
-    const unsigned sel = h.m.z >> (6u * k);
-    const float4 b0 = h.b0, b1 = h.b1, b2 = h.b2;
-    const float K0 = k ? b1.z : b0.x, K1 = k ? b1.w : b0.y, K2 = k ? b2.x : b0.z, K3 = k ? b2.y : b0.w, K4 = k ? b2.z : b1.x, K5 = k ? b2.w : b1.y;
-    const bool s0 = sel & 1u, s1 = sel & 2u, s2 = sel & 4u, s3 = sel & 8u, s4 = sel & 16u, s5 = sel & 32u;
-    d.b0 = make_float4(s0 ? n0.x : K0, s1 ? n0.y : K1, s2 ? n0.z : K2, s3 ? n0.w : K3);
-    d.b1 = make_float4(s4 ? n1.x : K4, s5 ? n1.y : K5, s0 ? K0 : n0.x, s1 ? K1 : n0.y);
-    d.b2 = make_float4(s2 ? K2 : n0.z, s3 ? K3 : n0.w, s4 ? K4 : n1.x, s5 ? K5 : n1.y);
-    d.meta = make_uint4(prt_f2u(n1.z), prt_f2u(n1.w), 0u, 0u);
-    return d;
-}
-PT_DEV PairData load_rec_visit(const NodeRec* __restrict__ recs, const unsigned node) {
-    const float4* q = reinterpret_cast<const float4*>(recs + (node >> 2));
-    const RecHead h = load_rec_head(q);
-    return rec_visit_data(h, q, node & 3u);
-}
-// node word of inner child k (meta word m) of the pair visited as `node`
-PT_DEV unsigned rec_child(const unsigned node, const unsigned k, const unsigned m) {
-    return (m & PT_REC_INLINE) ? ((node & ~3u) | (1u + k)) : (m << 2);
-}
-PT_DEV void rec_leaf(const DevScene& sc, const unsigned m, unsigned& first, unsigned& count) {
-    count = (m >> 26) & 31u; first = m & 0x3ffffffu;
-    if (count == 0u) { const uint2 e = sc.leaf_ext[first]; first = e.x; count = e.y; }
-}
 
-PT_DEV void walk_begin(const DevScene& sc, const bool ANY_HIT, const Ray& ray, const float tmax, const RayPre& p, WalkState& w,
-                       const TravStack& stack) {
-    w.found = false; w.done = false;
-    w.slot = 0;
-    if (!ANY_HIT) { w.t = tmax; w.u = w.v = 0.0f; }
-    float t_any = tmax;
-    TriHit th;
-    th.u = th.v = 0.0f; th.slot = 0;
-    w.node = 0; w.sp = 0;
-    if (sc.root_is_leaf) {
-        for (unsigned i = sc.root_leaf_first; i < sc.root_leaf_first + sc.root_leaf_count; ++i)
-            if (hit_triangle(sc.tri_geom, i, ray, ANY_HIT ? t_any : w.t, th)) { w.found = true; if (ANY_HIT) break; w.u = th.u; w.v = th.v; w.slot = th.slot; }
-        w.done = true;
-        return;
-    }
-    // the step at the root through the scalar cache (uniform address), as in the NodePair walk
-    const PairData d = load_rec_visit(sc.recs, 0u);
-    const PairTest pt = test_pair(d, p, ANY_HIT ? tmax : w.t);
-    const unsigned m0 = d.meta.x, m1 = d.meta.y;
-    if (!((pt.go0 & ((m0 >> 31) != 0u)) | (pt.go1 & ((m1 >> 31) != 0u)))) {
-        if (pt.go0 != pt.go1) {
-            w.node = pt.go0 ? rec_child(0u, 0u, m0) : rec_child(0u, 1u, m1);
-        } else if (pt.go0) {
-            unsigned nearc = rec_child(0u, 0u, m0), farc = rec_child(0u, 1u, m1);
-            if (pt.entry0 > pt.entry1) { const unsigned x = nearc; nearc = farc; farc = x; }
-            stack.lds[0] = farc;
-            w.sp = 1;
-            w.node = nearc;
-        } else {
-            w.done = true;
-        }
-    }
-}
-
-PT_DEV void walk_step(const DevScene& sc, const bool ANY_HIT, const Ray& ray, const RayPre& p, WalkState& w, const TravStack& stack) {
+// one triangle of the pending run (triangle.cl:4-43 through hit_triangle_data), on the record (a, b, c4) = tri_geom[w.pend_first]
+PT_DEV void walk_tri_data(const float4 a, const float4 b, const float4 c4, const bool ANY_HIT, const Ray& ray, WalkState& w) {
+    PT_WSTAT(ANY_HIT ? 3 : 1);
     float t_any = ray.t;
     TriHit th;
     th.u = th.v = 0.0f; th.slot = 0;
-#if PT_REC >= 2
-    unsigned node = w.node;
-    const float4* q = reinterpret_cast<const float4*>(sc.recs + (node >> 2));
-    const RecHead h = load_rec_head(q);
-    for (;;) {                                                   // a step into an inlined child goes on in the same call (at most twice)
-    const PairData d = rec_visit_data(h, q, node & 3u);
-#else
-    const unsigned node = w.node;
-    const PairData d = load_rec_visit(sc.recs, node);
-#endif
-    const PairTest pt = test_pair(d, p, ANY_HIT ? t_any : w.t);
-    const unsigned m0 = d.meta.x, m1 = d.meta.y;
-    bool go0 = pt.go0, go1 = pt.go1;
-    const bool hit_leaf0 = go0 & ((m0 >> 31) != 0u), hit_leaf1 = go1 & ((m1 >> 31) != 0u);
-    if (hit_leaf0 | hit_leaf1) {
-        unsigned f0 = 0, n0 = 0, f1 = 0, n1 = 0;
-        if (hit_leaf0) rec_leaf(sc, m0, f0, n0);
-        if (hit_leaf1) rec_leaf(sc, m1, f1, n1);
-        const unsigned n = n0 + n1;
-        for (unsigned k = 0; k < n; ++k) {
-            const unsigned i = k < n0 ? f0 + k : f1 + (k - n0);
-            if (hit_triangle(sc.tri_geom, i, ray, ANY_HIT ? t_any : w.t, th)) {
-                w.found = true;
-                if (ANY_HIT) { w.done = true; return; }
-                w.u = th.u; w.v = th.v; w.slot = th.slot;
-            }
-        }
-        if (hit_leaf0) go0 = false;
-        if (hit_leaf1) go1 = false;
+    const unsigned i = w.pend_first;
+    w.pend_first = i + 1u;
+    const unsigned left = w.pend_count - 1u;
+    w.pend_count = left;
+    if (hit_triangle_data(a, b, c4, i, ray, ANY_HIT ? t_any : w.t, th)) {
+        w.found = true;
+        if (ANY_HIT) { w.pend_count = 0; w.done = true; return; }
+        w.u = th.u; w.v = th.v; w.slot = th.slot;
     }
-    if (go0 != go1) {
-        w.node = go0 ? rec_child(node, 0u, m0) : rec_child(node, 1u, m1);
-    } else if (go0) {
-        unsigned nearc = rec_child(node, 0u, m0), farc = rec_child(node, 1u, m1);
-        if (pt.entry0 > pt.entry1) { const unsigned x = nearc; nearc = farc; farc = x; }
-        stack.lds[w.sp * stack.stride] = farc;
-        ++w.sp;
-        w.node = nearc;
-    } else {
-        if (w.sp == 0u) { w.done = true; return; }
-        --w.sp;
-        w.node = stack.lds[w.sp * stack.stride];
-        return;
-    }
-#if PT_REC >= 2
-    if ((w.node >> 2) != (node >> 2)) return;                    // another record: the next call fetches it
-    node = w.node;                                               // a child inlined in this record: its boxes are at hand
-    }
-#endif
+    if (left == 0u && w.last) w.done = true;
 }
-#endif  // PT_REC
+
+PT_DEV void walk_box(const DevScene& sc, const bool ANY_HIT, const Ray& ray, const RayPre& p, WalkState& w, const TravStack& stack) {
+    const PairData d = load_pair(sc.pairs, w.node);
+    walk_box_data(d, ANY_HIT, ray, p, w, stack);
+}
+PT_DEV void walk_tri(const DevScene& sc, const bool ANY_HIT, const Ray& ray, WalkState& w) {
+    const float4* q = reinterpret_cast<const float4*>(sc.tri_geom + w.pend_first);
+    const float4 a = q[0], b = q[1], c4 = q[2];
+    walk_tri_data(a, b, c4, ANY_HIT, ray, w);
+}
+// ONE unit of a lane's walk -- the box half of a step, or one pending triangle -- behind ONE memory access: a wave whose lanes are
+// at both kinds of unit waits for its loads once per iteration, not once per kind (the records are read through the same
+// instructions, the address is the lane's own)
+PT_DEV void walk_unit(const DevScene& sc, const bool ANY_HIT, const Ray& ray, const RayPre& p, WalkState& w, const TravStack& stack) {
+    const bool tri = w.pend_count != 0u;
+    const float4* q = tri ? reinterpret_cast<const float4*>(sc.tri_geom + w.pend_first) : reinterpret_cast<const float4*>(sc.pairs + w.node);
+    PairData d;
+    d.b0 = q[0]; d.b1 = q[1]; d.b2 = q[2];
+    d.meta = make_uint4(0u, 0u, 0u, 0u);
+    if (!tri) d.meta = *reinterpret_cast<const uint4*>(q + 3);
+    if (tri) walk_tri_data(d.b0, d.b1, d.b2, ANY_HIT, ray, w);
+    else walk_box_data(d, ANY_HIT, ray, p, w, stack);
+}
 
 // ---- sphere / quad, kernels/geometry/sphere.cl:5-41, quad.cl:11-38 ------------------------------
 PT_DEV bool hit_sphere(const DevSphere& s, const Ray& ray, float& best_t) {
@@ -1329,7 +1245,7 @@ PT_DEV void lane_init(Lane& L) {
     L.sampledLobe = 0u; L.sh_tmax = 0.0f; L.ps_pdf = 1.0f;
     L.rng.s0 = L.rng.s1 = 0u;
     L.h.t = 0.0f; L.h.normal = splat(0.0f); L.h.mesh_id = -1; L.h.didHit = L.h.backside = false; L.h_valid = false;
-    L.w.node = L.w.sp = 0u; L.w.t = 0.0f; L.w.u = L.w.v = 0.0f; L.w.slot = 0u; L.w.found = false; L.w.done = true;
+    L.w.node = 0u; L.w.sp = 0u; L.w.pend_count = 0u; L.w.pend_first = 0u; L.w.t = 0.0f; L.w.u = L.w.v = 0.0f; L.w.slot = 0u; L.w.found = false; L.w.done = true; L.w.last = false;
     L.f = 0u; L.stage = ST_READY;
     L.begun = L.fresh = L.w2 = L.occluded = false;
 }

@@ -41,6 +41,9 @@ using namespace dev;
 #ifndef PT_MIN_WAVES
 #define PT_MIN_WAVES 4
 #endif
+#ifndef PT_UNIFIED
+#define PT_UNIFIED 0        // a lane's box step and its pending triangle test share one load per iteration (0: box steps, then triangle tests)
+#endif
 #define PT_BLOCK 64         // threads per workgroup: ONE wave.  A workgroup's slot (LDS, dispatch) frees only when its last wave
                             // ends, and waves over the mesh run ~3x longer than waves over a wall: one-wave groups +4 % over 256
 
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene 
     extern __shared__ unsigned lds_stack[];                     // sc.stack_levels x PT_BLOCK, sized by the launch
     TravStack stk;
     stk.lds = lds_stack + threadIdx.x; stk.stride = PT_BLOCK;
-    const unsigned T = fa.walk_min_lanes, TD = fa.shadow_min_lanes;
+    const unsigned T = fa.walk_min_lanes, TD = fa.shadow_min_lanes, TQ = fa.tri_sixteenths;
 #ifdef PT_PHASE_CLOCKS
     unsigned long long clk_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_readcyclecounter();
     const unsigned long long start_ = last_;
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene 
 #ifdef PT_PHASE_CLOCKS
         done_lanes_ += (unsigned long long)__popcll(__ballot(!runnable && L.stage == ST_READY));
 #endif
-        if (runnable) lane_front<MATS, MEDIUM>(sc, cam, fa, L, gx, gy);                                  // A
+        if (runnable) { PT_WSTAT(4); lane_front<MATS, MEDIUM>(sc, cam, fa, L, gx, gy); }                // A
         PT_CLK(0);
         {                                                                                                 // B
             const bool walking = L.stage == ST_WALKC;
@@ -123,18 +126,37 @@ __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene 
             const unsigned n_start = (unsigned)__popcll(__ballot(go));
             const unsigned n_other = (unsigned)__popcll(__ballot((walking && L.w.done) || L.stage == ST_BACK));
             if (go) {
-                for (;;) {
-                    walk_step(sc, false, wr, p, L.w, stk);
+#if PT_UNIFIED
+                // every iteration a lane takes ONE unit of its walk (the box half of a step, or one pending triangle) behind one
+                // load; the lanes with a triangle pending sit iterations out until enough of the phase's lanes have one (the first
+                // iteration of a phase takes them anyway: a pending lane tests at least one triangle per iteration of the wave)
+                for (bool first = true;; first = false) {
+                    const bool pending = L.w.pend_count != 0u;
+                    const unsigned n_in = (unsigned)__popcll(__ballot(1)), n_pend = (unsigned)__popcll(__ballot(pending));
+                    if (!pending || first || n_pend * 16u >= n_in * TQ) walk_unit(sc, false, wr, p, L.w, stk);
                     if (L.w.done) break;
                     const unsigned n_act = (unsigned)__popcll(__ballot(1));
                     if (n_act < T && n_other + (n_start - n_act) > PT_WAIT_RATIO * n_act) break;   // the lanes that wait outnumber the walkers
                 }
+#else
+                for (;;) {
+                    if (!L.w.pend_count) walk_box(sc, false, wr, p, L.w, stk);
+                    // the triangles that the box steps found are tested once enough of the walking lanes have one pending (or the
+                    // phase is about to end: a pending lane tests at least one per iteration of the wave)
+                    const bool pending = L.w.pend_count != 0u;
+                    const unsigned n_in = (unsigned)__popcll(__ballot(1)), n_pend = (unsigned)__popcll(__ballot(pending));
+                    const unsigned n_act = (unsigned)__popcll(__ballot(!L.w.done));
+                    const bool cut = n_act < T && n_other + (n_start - n_act) > PT_WAIT_RATIO * n_act;   // the lanes that wait outnumber the walkers
+                    if (pending && (n_pend * 16u >= n_in * TQ || cut)) walk_tri(sc, false, wr, L.w);
+                    if (L.w.done || cut) break;
+                }
+#endif
             }
             PT_CLK(1);
-            if (walking && L.w.done) lane_closest_done<MATS, MEDIUM>(sc, L);
+            if (walking && L.w.done) { PT_WSTAT(5); lane_closest_done<MATS, MEDIUM>(sc, L); }
             PT_CLK(2);
         }
-        if (L.stage == ST_BACK) lane_back<MATS, MEDIUM>(sc, L);                                          // C
+        if (L.stage == ST_BACK) { PT_WSTAT(6); lane_back<MATS, MEDIUM>(sc, L); }                         // C
         PT_CLK(3);
         {                                                                                                 // D
             const bool walking = L.stage == ST_WALKS;
@@ -145,17 +167,34 @@ __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene 
             const unsigned n_start = (unsigned)__popcll(__ballot(go));
             const unsigned n_other = (unsigned)__popcll(__ballot((walking && L.w.done) || L.stage == ST_FINISH));
             if (go) {
-                for (;;) {
-                    walk_step(sc, true, wr, p, L.w, stk);
+#if PT_UNIFIED
+                // every iteration a lane takes ONE unit of its walk (the box half of a step, or one pending triangle) behind one
+                // load; the lanes with a triangle pending sit iterations out until enough of the phase's lanes have one (the first
+                // iteration of a phase takes them anyway: a pending lane tests at least one triangle per iteration of the wave)
+                for (bool first = true;; first = false) {
+                    const bool pending = L.w.pend_count != 0u;
+                    const unsigned n_in = (unsigned)__popcll(__ballot(1)), n_pend = (unsigned)__popcll(__ballot(pending));
+                    if (!pending || first || n_pend * 16u >= n_in * TQ) walk_unit(sc, true, wr, p, L.w, stk);
                     if (L.w.done) break;
                     const unsigned n_act = (unsigned)__popcll(__ballot(1));
-                    if (n_act < TD && n_other + (n_start - n_act) > PT_WAIT_RATIO * n_act) break;
+                    if (n_act < TD && n_other + (n_start - n_act) > PT_WAIT_RATIO * n_act) break;   // the lanes that wait outnumber the walkers
                 }
+#else
+                for (;;) {
+                    if (!L.w.pend_count) walk_box(sc, true, wr, p, L.w, stk);
+                    const bool pending = L.w.pend_count != 0u;
+                    const unsigned n_in = (unsigned)__popcll(__ballot(1)), n_pend = (unsigned)__popcll(__ballot(pending));
+                    const unsigned n_act = (unsigned)__popcll(__ballot(!L.w.done));
+                    const bool cut = n_act < TD && n_other + (n_start - n_act) > PT_WAIT_RATIO * n_act;
+                    if (pending && (n_pend * 16u >= n_in * TQ || cut)) walk_tri(sc, true, wr, L.w);
+                    if (L.w.done || cut) break;
+                }
+#endif
             }
             if (walking && L.w.done) { L.occluded = L.w.found; L.stage = ST_FINISH; }
         }
         PT_CLK(4);
-        if (L.stage == ST_FINISH) lane_finish<MATS, MEDIUM>(sc, L);                                            // E
+        if (L.stage == ST_FINISH) { PT_WSTAT(7); lane_finish<MATS, MEDIUM>(sc, L); }                           // E
         PT_CLK(5);
 #ifdef PT_PHASE_CLOCKS
         ++clk_[6];
@@ -419,12 +458,15 @@ void dump_phase_clocks() {
         else fprintf(stderr, "phase clocks: %-16s %5.1f %%\n", names[k], 100.0 * (double)h[k] / tot);
     if (h[10]) fprintf(stderr, "phase clocks: waves %llu, iterations per wave mean %.0f max %llu, cycles per wave mean %.0f max %llu\n", h[10],
                        (double)h[6] / (double)h[10], h[8], tot / (double)h[10], h[9]);
-    unsigned long long ws[8] = {0};
+#ifdef PT_WALK_STATS
+    unsigned long long ws[16] = {0};
     if (hipMemcpyFromSymbol(ws, HIP_SYMBOL(dev::g_walk_stats), sizeof(ws)) == hipSuccess) {
-        const char* wn[4] = {"closest box steps", "closest triangle iterations", "any-hit box steps", "any-hit triangle iterations"};
-        for (int k = 0; k < 4; ++k)
+        const char* wn[8] = {"closest box steps", "closest triangle iterations", "any-hit box steps", "any-hit triangle iterations",
+                             "A lane_front", "B lane_closest_done", "C lane_back", "E lane_finish"};
+        for (int k = 0; k < 8; ++k)
             fprintf(stderr, "phase clocks: %-28s %llu wave-level, %.1f lanes each\n", wn[k], ws[2 * k], ws[2 * k] ? (double)ws[2 * k + 1] / (double)ws[2 * k] : 0.0);
     }
+#endif
     if (h[6]) fprintf(stderr, "phase clocks: lanes that have done their frames (or their samples) and wait for the wave: %.1f %% of the lane-iterations\n",
                       100.0 * (double)h[11] / (64.0 * (double)h[6]));
 }

@@ -33,30 +33,6 @@ struct alignas(16) NodePair {
 };
 static_assert(sizeof(NodePair) == 64, "NodePair");
 
-// NodeRec 128 B = one cache line: a NodePair AND, for each inner child the packer chose to INLINE, that child's own pair.
-// A walk that steps from the pair into an inlined child finds the child's boxes in the line it has just fetched: one
-// memory round trip for two levels of the tree (an 871 k-triangle mesh: 23 levels, each a dependent L2 / Infinity-Cache
-// access in the NodePair layout).  The grandchildren's boxes are stored without loss in 6 floats instead of 12: a node's
-// box is the union of its children's, so each of its 6 planes IS (bit for bit) the same plane of one child -- `sel` says
-// of which, `nw` holds the other child's plane.  A child whose planes do not reproduce its box bit for bit (a caller's
-// tree with slack, a -0.0 against a +0.0) is simply not inlined.  Same boxes, same tests, same visiting order as the
-// reference (kernels/geometry/bvh.cl:132-206): only where the bytes come from changes.
-//   meta word of a child:  inner, its own record    0 0 <record index: 30 bits>
-//                          inner, inlined here      0 1 0...
-//                          leaf                     1 <count: 5 bits> <first slot: 26 bits>     count 1..31
-//                          leaf (does not fit)      1 00000 <index into leaf_ext[] = {first slot, count}>
-//   a walk's node word (WalkState::node, traversal stack) = record * 4 + (0: the record's pair; 1 + k: its inlined child k)
-struct alignas(128) NodeRec {
-    float b[12];                 // as NodePair::b: boxes of the pair's children c0, c1
-    uint32_t meta[2];            // c0, c1
-    uint32_t sel;                // bit 6k + j: plane j of inlined child k's FIRST child is nw[j] (its second child's is c_k's); clear: the other way round
-    uint32_t _pad;
-    struct { float nw[6]; uint32_t meta[2]; } in[2];     // inlined child k: the 6 planes that are not c_k's own, and its children
-};
-static_assert(sizeof(NodeRec) == 128, "NodeRec");
-#define PT_REC_INLINE 0x40000000u
-#define PT_REC_LEAF 0x80000000u
-
 struct alignas(16) TriGeom { float p0[3]; float e1[3]; float e2[3]; float n[3]; };
 struct alignas(16) TriNrm { float n0[4]; float n1[4]; float n2[4]; };
 static_assert(sizeof(TriGeom) == 48 && sizeof(TriNrm) == 48, "Tri records");
@@ -99,9 +75,6 @@ static_assert(sizeof(DevSphere) == 16 && sizeof(DevQuad) == 80 && sizeof(DevMate
 struct DevScene {
     const NodePair* pairs;          // breadth-first order
     uint32_t n_pairs;
-    const NodeRec* recs;            // the same tree as two-level records (what the walks read); recs[0] holds the root pair
-    const uint2* leaf_ext;          // {first slot, count} of the leaves a meta word cannot hold
-    uint32_t n_recs;
     const TriGeom* tri_geom;
     const TriNrm* tri_nrm;
     const DevSphere* spheres;
@@ -163,6 +136,7 @@ struct FrameArgs {
     uint32_t scatter;                       // set by the launcher: lane l of wave g renders pixel l of tile (l * waves + g) / 64 ...
     uint32_t walk_min_lanes;                // lane machine: a closest-hit walk phase of a wave ends once fewer lanes than this are still walking
     uint32_t shadow_min_lanes;              // ... and an any-hit (shadow ray) phase below this many
+    uint32_t tri_sixteenths;                // the pending triangle tests of a walk phase run once this many sixteenths of its walking lanes have one
 };
 
 }  // namespace prt

@@ -4,7 +4,6 @@
 #include "pt_pack.h"
 
 #include <cmath>
-#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <utility>
@@ -20,106 +19,6 @@ static DevMaterial pack_material(const prt_material& m) {
     return d;
 }
 
-// ---- NodePair tree -> two-level NodeRec records (pt_layout.h)
-// Which inner children are inlined into their parent's record is chosen by a dynamic programme over the tree that minimises
-// the expected number of cache lines a walk fetches: a record costs the probability that a ray visits its root pair
-// (proportional to the surface area of the pair's box), an inlined pair costs a fraction of that (its line is the one
-// just fetched), and an inlined pair's own inner children must start records of their own.
-static inline uint32_t f2u(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
-static void build_records(const std::vector<NodePair>& pairs, std::vector<NodeRec>& recs, std::vector<uint2>& leaf_ext) {
-    const size_t n = pairs.size();
-    recs.clear(); leaf_ext.clear();
-    if (!n) return;
-    auto inner = [&](const NodePair& p, int k) { return p.meta[2 * k + 1] == 0xFFFFFFFFu; };
-    // can the pair behind child k of p be stored as 6 planes + 6 selector bits?  (sel: bit j set = the FIRST grandchild's plane j is the new one)
-    auto sharing = [&](const NodePair& p, int k, uint32_t& sel) {
-        const NodePair& c = pairs[p.meta[2 * k]];
-        sel = 0;
-        for (int j = 0; j < 6; ++j) {
-            const uint32_t K = f2u(p.b[6 * k + j]), g0 = f2u(c.b[j]), g1 = f2u(c.b[6 + j]);
-            if (g0 == K) continue;                      // first grandchild has the parent's plane, the second's is stored
-            if (g1 == K) { sel |= 1u << j; continue; }
-            return false;
-        }
-        return true;
-    };
-    double alpha = 0.35;                                 // an inlined visit (same line again) against a fresh line
-    if (const char* e = std::getenv("PRT_REC_ALPHA")) alpha = std::atof(e);
-    const bool no_inline = std::getenv("PRT_REC_NO_INLINE") != nullptr;     // development: every pair its own record
-    std::vector<double> w(n), cost_root(n), cost_inl(n);
-    for (size_t i = n; i-- > 0;) {                       // children have larger indices than their parents (bfs and dfs order alike)
-        const NodePair& p = pairs[i];
-        float lo[3], hi[3];
-        for (int a = 0; a < 3; ++a) { lo[a] = std::fmin(p.b[2 * a], p.b[6 + 2 * a]); hi[a] = std::fmax(p.b[2 * a + 1], p.b[6 + 2 * a + 1]); }
-        const double dx = (double)hi[0] - lo[0], dy = (double)hi[1] - lo[1], dz = (double)hi[2] - lo[2];
-        w[i] = (dx + dy) * dz + dx * dy;
-        if (!(w[i] > 0.0)) w[i] = 1e-30;
-        double cr = w[i], ci = alpha * w[i];
-        for (int k = 0; k < 2; ++k) {
-            if (!inner(p, k)) continue;
-            const uint32_t ch = p.meta[2 * k];
-            uint32_t sel;
-            const bool feas = !no_inline && sharing(p, k, sel);
-            cr += (feas && cost_inl[ch] < cost_root[ch]) ? cost_inl[ch] : cost_root[ch];
-            ci += cost_root[ch];
-        }
-        cost_root[i] = cr; cost_inl[i] = ci;
-    }
-    // roles top-down, record indices in the order of the pairs (bfs for small trees, pre-order dfs for big ones: pt_pack's `order`)
-    std::vector<uint32_t> rec_of(n, 0xFFFFFFFFu);
-    std::vector<uint8_t> inl(n, 0);
-    std::vector<uint32_t> roots;
-    roots.reserve(n / 2 + 1);
-    {
-        std::vector<uint8_t> is_root(n, 0);
-        is_root[0] = 1;
-        for (size_t i = 0; i < n; ++i) {
-            const NodePair& p = pairs[i];
-            for (int k = 0; k < 2; ++k) {
-                if (!inner(p, k)) continue;
-                const uint32_t ch = p.meta[2 * k];
-                uint32_t sel;
-                if (is_root[i] && !no_inline && sharing(p, k, sel) && cost_inl[ch] < cost_root[ch]) inl[ch] = 1;
-                else is_root[ch] = 1;
-            }
-        }
-        for (size_t i = 0; i < n; ++i) if (is_root[i]) { rec_of[i] = (uint32_t)roots.size(); roots.push_back((uint32_t)i); }
-    }
-    auto leaf_meta = [&](uint32_t first, uint32_t count) -> uint32_t {
-        if (count >= 1 && count <= 31 && first < (1u << 26)) return PT_REC_LEAF | (count << 26) | first;
-        leaf_ext.push_back(make_uint2(first, count));
-        return PT_REC_LEAF | (uint32_t)(leaf_ext.size() - 1);
-    };
-    if (std::getenv("PRT_REC_STATS")) {
-        size_t n_inl = 0;
-        for (size_t i = 0; i < n; ++i) n_inl += inl[i];
-        double wr = 0, wi = 0;
-        for (size_t i = 0; i < n; ++i) (inl[i] ? wi : wr) += w[i];
-        std::fprintf(stderr, "records: %zu pairs -> %zu records (%zu pairs inlined), %.1f MB instead of %.1f MB; area-weighted visits: %.1f %% inlined\n", n, roots.size(), n_inl,
-                     roots.size() * 128e-6, n * 64e-6, 100.0 * wi / (wi + wr));
-    }
-    recs.assign(roots.size(), NodeRec{});
-    for (size_t r = 0; r < roots.size(); ++r) {
-        const NodePair& p = pairs[roots[r]];
-        NodeRec& R = recs[r];
-        std::memset(&R, 0, sizeof(R));
-        for (int j = 0; j < 12; ++j) R.b[j] = p.b[j];
-        for (int k = 0; k < 2; ++k) {
-            if (!inner(p, k)) { R.meta[k] = leaf_meta(p.meta[2 * k], p.meta[2 * k + 1]); continue; }
-            const uint32_t ch = p.meta[2 * k];
-            if (!inl[ch]) { R.meta[k] = rec_of[ch]; continue; }
-            R.meta[k] = PT_REC_INLINE;
-            uint32_t sel = 0;
-            (void)sharing(p, k, sel);
-            R.sel |= sel << (6 * k);
-            const NodePair& cp = pairs[ch];
-            for (int j = 0; j < 6; ++j) R.in[k].nw[j] = ((sel >> j) & 1u) ? cp.b[j] : cp.b[6 + j];
-            for (int g = 0; g < 2; ++g)
-                R.in[k].meta[g] = inner(cp, g) ? rec_of[cp.meta[2 * g]] : leaf_meta(cp.meta[2 * g], cp.meta[2 * g + 1]);
-        }
-    }
-}
-
 int pack_scene(const prt_config& cfg, const prt_scene_desc* s, PackedScene& out, std::string& err) {
     auto fail = [&err](int, int code, const char* msg) { err = msg; return code; };
     const int c = 0;
@@ -132,7 +31,7 @@ int pack_scene(const prt_config& cfg, const prt_scene_desc* s, PackedScene& out,
     if (n_mesh && !s->meshes) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: meshes is null");
     if (n_mesh >= (1u << 23)) return fail(c, PRT_ERR_UNSUPPORTED, "prt_upload_scene: 2^23 primitives or more (a hit record keeps the mesh index in 24 bits)");
     const uint32_t T = s->triangle_count, N = s->bvh_node_count;
-    if (T >= (1u << 30)) return fail(c, PRT_ERR_UNSUPPORTED, "prt_upload_scene: 2^30 triangles or more");
+    if (T >= (1u << 29)) return fail(c, PRT_ERR_UNSUPPORTED, "prt_upload_scene: 2^29 triangles or more");
     if (T && (!s->vertices || !s->normals || !s->primitive_indices || !s->bvh_nodes || !N))
         return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: triangle buffers incomplete");
 
@@ -170,12 +69,23 @@ int pack_scene(const prt_config& cfg, const prt_scene_desc* s, PackedScene& out,
     DevScene sc{};
     sc.root_is_leaf = 1;
     sc.stack_levels = 1;
+    // Triangle SLOTS: the triangles are gathered leaf by leaf in the order of the NodePair records, a pair's left leaf child
+    // first, so that the leaves a walk step finds are ONE run of slots (pt_device.h walk_box / walk_tri).  slot_src[slot] =
+    // position in primitive_indices.  A tree whose leaves share triangles gets one slot per reference (bounded: 4 x T).
+    std::vector<uint32_t> slot_src;
+    const uint64_t max_slots = 4ull * T < (1ull << 29) ? 4ull * T : (1ull << 29) - 1;
+    auto add_leaf = [&](const prt_bvh_node& nd, uint32_t& first_slot) {
+        if ((uint64_t)slot_src.size() + nd.primitive_count > max_slots) return false;
+        first_slot = (uint32_t)slot_src.size();
+        for (uint32_t j = 0; j < nd.primitive_count; ++j) slot_src.push_back(nd.first_child_or_primitive + j);
+        return true;
+    };
     if (T) {
         const prt_bvh_node* nodes = s->bvh_nodes;
         auto leaf_ok = [&](const prt_bvh_node& nd) { return (uint64_t)nd.first_child_or_primitive + nd.primitive_count <= T; };
         if (nodes[0].is_leaf) {
             if (!leaf_ok(nodes[0])) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: root leaf range out of bounds");
-            sc.root_leaf_first = nodes[0].first_child_or_primitive;
+            if (!add_leaf(nodes[0], sc.root_leaf_first)) return fail(c, PRT_ERR_UNSUPPORTED, "prt_upload_scene: the leaves reference more than 4 x the triangles");
             sc.root_leaf_count = nodes[0].primitive_count;
         } else {
             sc.root_is_leaf = 0;
@@ -225,7 +135,7 @@ int pack_scene(const prt_config& cfg, const prt_scene_desc* s, PackedScene& out,
                     if (cn.is_leaf) {
                         if (!leaf_ok(cn)) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: leaf range out of bounds");
                         if (cn.primitive_count == 0xFFFFFFFFu) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: bad leaf");
-                        p.meta[2 * ch] = cn.first_child_or_primitive;
+                        if (!add_leaf(cn, p.meta[2 * ch])) return fail(c, PRT_ERR_UNSUPPORTED, "prt_upload_scene: the leaves reference more than 4 x the triangles");
                         p.meta[2 * ch + 1] = cn.primitive_count;
                     } else {
                         p.meta[2 * ch] = pair_of[nd.first_child_or_primitive + ch];
@@ -249,18 +159,19 @@ int pack_scene(const prt_config& cfg, const prt_scene_desc* s, PackedScene& out,
             }
             if (max_sp > 64u) return fail(c, PRT_ERR_UNSUPPORTED, "prt_upload_scene: BVH needs more than the 64 traversal-stack entries of the reference (bvh.cl:131)");
             sc.stack_levels = max_sp + 1;
-            build_records(pairs, out.recs, out.leaf_ext);
         }
     } else {
         sc.root_leaf_first = 0; sc.root_leaf_count = 0;        // "no OBJ" = empty leaf root
     }
-    // ---- triangles in leaf-slot order
+    // ---- triangles in slot order
     std::vector<TriGeom>& tg = out.tg;
     std::vector<TriNrm>& tn = out.tn;
-    tg.assign(T, TriGeom{}); tn.assign(T, TriNrm{});
-    for (uint32_t i = 0; i < T; ++i) {
-        const uint32_t fv = (uint32_t)s->primitive_indices[i] * 3u;        // triangle.cl:7 (uint arithmetic)
-        if ((uint64_t)fv + 2 >= (uint64_t)T * 3) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: primitive index out of range");
+    const size_t S = slot_src.size();
+    for (uint32_t i = 0; i < T; ++i)
+        if ((uint64_t)((uint32_t)s->primitive_indices[i] * 3u) + 2 >= (uint64_t)T * 3) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: primitive index out of range");
+    tg.assign(S, TriGeom{}); tn.assign(S, TriNrm{});
+    for (size_t i = 0; i < S; ++i) {
+        const uint32_t fv = (uint32_t)s->primitive_indices[slot_src[i]] * 3u;        // triangle.cl:7 (uint arithmetic)
         const float* p0 = s->vertices + 4 * (size_t)fv;
         const float* p1 = p0 + 4; const float* p2 = p0 + 8;
         TriGeom& g = tg[i];
@@ -276,7 +187,6 @@ int pack_scene(const prt_config& cfg, const prt_scene_desc* s, PackedScene& out,
     }
 
     sc.n_pairs = (uint32_t)pairs.size();
-    sc.n_recs = (uint32_t)out.recs.size();
     sc.n_spheres = n_sph; sc.n_quads = n_quad; sc.quad_mesh_base = n_sph + n_sdf; sc.n_meshes = n_mesh; sc.n_sdfs = n_sdf;
     sc.marching_steps = cfg.marching_steps; sc.shadow_marching_steps = cfg.shadow_marching_steps;
     sc.light_sphere = sc.light_quad = 0xFFFFFFFFu; sc.light_mesh = 0;

@@ -12,8 +12,6 @@ namespace prt {
 
 struct PackedScene {
     std::vector<NodePair> pairs;
-    std::vector<NodeRec> recs;           // the same tree as two-level records
-    std::vector<uint2> leaf_ext;
     std::vector<TriGeom> tg;
     std::vector<TriNrm> tn;
     std::vector<DevSphere> spheres;

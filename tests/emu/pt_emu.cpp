@@ -84,16 +84,25 @@ void run_tile(const DevScene& sc, const DevCamera& cam, const FrameArgs& fa, int
             n_other += ((walking && l.w.done) || l.stage == waiting_stage) ? 1u : 0u;
         }
         const unsigned T = phase_T();
-        for (;;) {
-            unsigned n_act = 0;
-            bool stepped = false;
+        const unsigned TQ = sched_seed ? xs.next() % 17u : fa.tri_sixteenths;        // a random share of pending lanes starts the triangle tests
+        for (bool first = true;; first = false) {
+            // render_kernel's loop: every iteration a lane takes one unit of its walk (walk_unit: the box half of a step, or one
+            // pending triangle); lanes with a triangle pending sit iterations out until enough of the lanes in the loop have one
+            unsigned n_in = 0, n_pend = 0;
             for (int lane = 0; lane < 64; ++lane) {
                 if (!go[lane]) continue;
-                walk_step(sc, any_hit, wr[lane], p[lane], L[lane].w, stk[lane]);
-                stepped = true;
+                ++n_in;
+                if (L[lane].w.pend_count) ++n_pend;
+            }
+            if (!n_in) break;
+            const bool tri = first || n_pend * 16u >= n_in * TQ;
+            unsigned n_act = 0;
+            for (int lane = 0; lane < 64; ++lane) {
+                if (!go[lane]) continue;
+                if (!L[lane].w.pend_count || tri) walk_unit(sc, any_hit, wr[lane], p[lane], L[lane].w, stk[lane]);
                 if (L[lane].w.done) go[lane] = false; else ++n_act;
             }
-            if (!stepped || n_act == 0) break;
+            if (n_act == 0) break;
             if (n_act < T && n_other + (n_start - n_act) > n_act) break;      // render_kernel's rule (PT_WAIT_RATIO 1)
         }
     };
@@ -157,7 +166,7 @@ extern "C" int emu_render(const prt_config* cfg, const prt_scene_desc* desc, con
         return rc;
     }
     DevScene sc = ps.sc;
-    sc.pairs = ps.pairs.data(); sc.recs = ps.recs.data(); sc.leaf_ext = ps.leaf_ext.data(); sc.tri_geom = ps.tg.data(); sc.tri_nrm = ps.tn.data();
+    sc.pairs = ps.pairs.data(); sc.tri_geom = ps.tg.data(); sc.tri_nrm = ps.tn.data();
     sc.spheres = ps.spheres.data(); sc.quads = ps.quads.data(); sc.sdfs = ps.sdfs.data(); sc.mats = ps.mats.data();
     static const float black[3] = {0.f, 0.f, 0.f};
     sc.env = env_rgb ? env_rgb : black; sc.env_w = env_rgb ? env_w : 1; sc.env_h = env_rgb ? env_h : 1;
@@ -170,6 +179,7 @@ extern "C" int emu_render(const prt_config* cfg, const prt_scene_desc* desc, con
     fa.seed_frames = (ahead && seed_frames > n_frames) ? seed_frames : n_frames; fa.run_ahead = ahead ? 1u : 0u;
     fa.unfinished = nullptr; fa.unfinished_host = nullptr; fa.tile_first = 0; fa.tile_stride = 1;
     fa.walk_min_lanes = walk_min_lanes ? walk_min_lanes : 8;
+    fa.tri_sixteenths = 4;
     constexpr unsigned LD = PRT_MAT_LIGHT | PRT_MAT_DIFF;
     std::vector<unsigned> stack_mem;
     const int tiles_x = (width + 7) / 8, tiles_y = (rows + 7) / 8;
