@@ -170,6 +170,23 @@ int prt_render_spp(prt_ctx* ctx, uint32_t spp, uint32_t max_frames, const int32_
  * phases 1 in small trees and the same as above in big ones (PRT_SHADOW_MIN_LANES).  A call of this function sets both. */
 int prt_set_walk_min_lanes(prt_ctx* ctx, uint32_t lanes);
 
+/* Build and schedule choices of a context (no counterpart in the reference; NONE changes a bit of any result -- the tests render
+ * the goldens under each).  For tests, experiments and tuning.  prt_create reads the same names from the environment, in upper
+ * case with the prefix PRT_.
+ *   "waves"             0 (default: chosen per launch) | 5 | 6   build of the render kernel: waves per SIMD its registers leave room for
+ *   "scatter"           -1 (default: chosen per launch) | 0 | 1  a wave renders one 8x8 tile | 64 pixels scattered over the launch's tiles
+ *   "generic"           0 | 1   1: the material set dispatched at run time even where the scene's own ACTIVE_MATS is compiled (the
+ *                               reference compiles exactly the scene's set, include/CL/cl_kernel.h:226-345; compiled here: LIGHT|DIFF,
+ *                               +COAT, +ROUGH_COND, +DIEL|ROUGH_DIEL)
+ *   "walk_min_lanes", "shadow_min_lanes"   0 (by launch) .. 64   see prt_set_walk_min_lanes
+ *   "tri_q"             0 .. 16  the triangle tests that a walk phase's box steps found run once this many sixteenths of its walking
+ *                               lanes have one pending (default 4)
+ *   "frames_per_launch" >= 1    frames one launch of the render kernel covers (default 512)
+ *   "run_ahead"         0 | 1   prt_render_spp: see there */
+int prt_set_option(prt_ctx* ctx, const char* name, int value);
+/* what the last launch ran, as text: "render_kernel<LIGHT|DIFF> waves=6 pixels=tiles" ("" before the first launch) */
+const char* prt_kernel_variant(prt_ctx* ctx);
+
 int prt_synchronize(prt_ctx* ctx);
 
 /* output texture: linear float4 acc/samples per pixel (kernels/main.cl:159).  Row 0 is the BOTTOM of the

@@ -201,6 +201,12 @@ class Renderer:
     def set_walk_min_lanes(self, lanes):
         self._chk(self.lib.prt_set_walk_min_lanes(self.ctx, int(lanes)), "prt_set_walk_min_lanes")
 
+    def set_option(self, name, value):
+        self._chk(self.lib.prt_set_option(self.ctx, name.encode(), int(value)), "prt_set_option")
+
+    def kernel_variant(self):
+        return self.lib.prt_kernel_variant(self.ctx).decode()
+
     def synchronize(self):
         self._chk(self.lib.prt_synchronize(self.ctx), "prt_synchronize")
 

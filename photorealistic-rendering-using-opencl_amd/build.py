@@ -18,7 +18,9 @@ COMMON = ["-std=c++17", "-O3", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "
           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(CSRC, "host"), "-I" + os.path.join(CSRC, "hip")]
 
 HOST_SOURCES = ["host/scene.cpp", "host/camera.cpp", "host/model_loader.cpp", "host/bvh.cpp", "host/hdr_loader.cpp", "host/host_capi.cpp"]
-HIP_SOURCES = ["hip/prt_api.cpp", "hip/pt_pack.cpp", "hip/pt_kernels.hip"]
+# the render kernel is instantiated per compile-time material set in a file of its own (pt_inst_*.hip): they compile in parallel
+HIP_SOURCES = ["hip/prt_api.cpp", "hip/pt_pack.cpp", "hip/pt_kernels.hip"] + \
+    ["hip/pt_inst_%s.hip" % k for k in ("light_diff", "coat", "rough_cond", "rough_diel", "generic", "sdf", "view", "view_sdf")]
 
 
 def newer(src, obj, deps):
@@ -44,6 +46,7 @@ def build(verbose=False, extra_hip_flags=()):
     headers += [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include"))]
     headers.append(os.path.abspath(__file__))           # the flags live here
     objs = []
+    jobs = []
     for s in HOST_SOURCES + HIP_SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(OBJ, s.replace("/", "_") + ".o")
@@ -56,10 +59,13 @@ def build(verbose=False, extra_hip_flags=()):
             cmd = [HIPCC] + COMMON + ["-fno-slp-vectorize", "-x", "hip", "--offload-arch=" + ARCH] + list(extra_hip_flags)
         else:
             cmd = [HOSTCXX] + COMMON
-        cmd += ["-c", src, "-o", obj]
-        out = run(cmd)
-        if verbose and out.strip():
-            print(out)
+        jobs.append(cmd + ["-c", src, "-o", obj])
+    if jobs:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), int(os.environ.get("PRT_BUILD_JOBS", "0")) or (os.cpu_count() or 4)))) as pool:
+            for out in pool.map(run, jobs):
+                if verbose and out.strip():
+                    print(out)
     lib = os.path.join(HERE, "libprt.so")
     if (not os.path.exists(lib)) or any(os.path.getmtime(o) > os.path.getmtime(lib) for o in objs):
         run([HIPCC, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", lib] + objs)

@@ -66,7 +66,9 @@ struct prt_ctx {
     uint32_t run_ahead = 1;                        // FrameArgs::run_ahead of prt_render_spp's launches (PRT_RUN_AHEAD=0: off)
     prt_stats stats{};
     std::string err;
-    const char* variant = "";
+    LaunchOpts lo{};                               // forced wave-count build / pixel mapping / generic material set (prt_set_option)
+    RenderLaunch last{};                           // what the last launch ran
+    std::string variant;                           // ... as text (prt_kernel_variant)
 };
 
 #define CTX_CHECK(ctx) do { if (!(ctx)) return PRT_ERR_INVALID_ARGUMENT; } while (0)
@@ -126,6 +128,9 @@ extern "C" int prt_create(int device, const prt_config* cfg, prt_ctx** out) {
     if (const char* ev = std::getenv("PRT_FRAMES_PER_LAUNCH")) { const int k = std::atoi(ev); if (k >= 1) c->frames_per_launch = (unsigned)k; }
     if (const char* ev = std::getenv("PRT_RUN_AHEAD")) c->run_ahead = std::atoi(ev) != 0 ? 1u : 0u;
     if (const char* ev = std::getenv("PRT_WALK_MIN_LANES")) { const int k = std::atoi(ev); if (k >= 1 && k <= 64) c->walk_min_lanes = (uint32_t)k; }
+    if (const char* ev = std::getenv("PRT_WAVES")) { const int k = std::atoi(ev); if (k == 5 || k == 6) c->lo.waves = k; }
+    if (const char* ev = std::getenv("PRT_SCATTER")) { const int k = std::atoi(ev); if (k == 0 || k == 1) c->lo.scatter = k; }
+    if (const char* ev = std::getenv("PRT_GENERIC")) c->lo.generic = std::atoi(ev) != 0 ? 1 : 0;
     if (const char* ev = std::getenv("PRT_TRI_Q")) { const int k = std::atoi(ev); if (k >= 0 && k <= 16) c->tri_sixteenths = (uint32_t)k; }
     if (const char* ev = std::getenv("PRT_SHADOW_MIN_LANES")) { const int k = std::atoi(ev); if (k >= 1 && k <= 64) c->shadow_min_lanes = (uint32_t)k; }
     *out = c;
@@ -374,7 +379,7 @@ extern "C" int prt_render_frames(prt_ctx* c, uint32_t first_frame, uint32_t n_fr
         for (int j = 0; j < K; ++j) {
             FrameArgs fa = frame_args(c, first_frame + f, n, c->d_seeds + 2 * (size_t)f, 0, false);
             fa.tile_first = (uint32_t)j; fa.tile_stride = (uint32_t)K;
-            c->variant = launch_render(c->sc, c->cam, c->S, fa, c->fb, K > 1 ? c->sub_stream[j] : c->stream);
+            c->last = launch_render(c->sc, c->cam, c->S, fa, c->fb, K > 1 ? c->sub_stream[j] : c->stream, c->lo);
             ++c->stats.launches;
         }
     }
@@ -406,7 +411,7 @@ extern "C" int prt_render_spp(prt_ctx* c, uint32_t spp, uint32_t max_frames, con
             HIPCHK(c, hipMemsetAsync(c->d_counters, 0, sizeof(unsigned long long), c->stream));
             FrameArgs fa = frame_args(c, 1 + f, n, c->d_seeds + 2 * (size_t)f, spp, true);
             fa.seed_frames = max_frames - f; fa.run_ahead = c->run_ahead;
-            c->variant = launch_render(c->sc, c->cam, c->S, fa, c->fb, c->stream);
+            c->last = launch_render(c->sc, c->cam, c->S, fa, c->fb, c->stream, c->lo);
             ++c->stats.launches;
             f += n;
             HIPCHK(c, hipMemcpyAsync(&unfinished, c->d_counters, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
@@ -455,7 +460,7 @@ extern "C" int prt_render_spp(prt_ctx* c, uint32_t spp, uint32_t max_frames, con
                     fa.tile_first = (uint32_t)j; fa.tile_stride = (uint32_t)K;
                     c->h_unfinished[2 * j + slot] = ~0ull;
                     SUBCHK(hipEventRecord(c->sub_ev0[j][slot], c->sub_stream[j]));
-                    c->variant = launch_render(c->sc, c->cam, c->S, fa, c->fb, c->sub_stream[j]);
+                    c->last = launch_render(c->sc, c->cam, c->S, fa, c->fb, c->sub_stream[j], c->lo);
                     SUBCHK(hipEventRecord(c->sub_ev[j][slot], c->sub_stream[j]));
                     ++c->stats.launches;
                     fj[j] += n;
@@ -506,6 +511,32 @@ extern "C" int prt_set_walk_min_lanes(prt_ctx* c, uint32_t lanes) {
     c->walk_min_lanes = lanes;
     c->shadow_min_lanes = lanes;                    // an explicit setting applies to both kinds of walk phase
     return PRT_OK;
+}
+
+// Schedule and build choices of a context.  None of them changes a bit of any result (the tests render the goldens under each);
+// they exist for tests, experiments and tuning.  The same names in upper case with the prefix PRT_ are read from the environment
+// by prt_create.
+extern "C" int prt_set_option(prt_ctx* c, const char* name, int value) {
+    CTX_CHECK(c);
+    if (!name) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_set_option: null name");
+    const std::string n(name);
+    auto bad = [&]() { return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_set_option: value out of range for " + n); };
+    if (n == "waves") { if (value != 0 && value != 5 && value != 6) return bad(); c->lo.waves = value; }
+    else if (n == "scatter") { if (value < -1 || value > 1) return bad(); c->lo.scatter = value; }
+    else if (n == "generic") { if (value < 0 || value > 1) return bad(); c->lo.generic = value; }
+    else if (n == "walk_min_lanes") { if (value < 0 || value > 64) return bad(); c->walk_min_lanes = (uint32_t)value; }
+    else if (n == "shadow_min_lanes") { if (value < 0 || value > 64) return bad(); c->shadow_min_lanes = (uint32_t)value; }
+    else if (n == "tri_q") { if (value < 0 || value > 16) return bad(); c->tri_sixteenths = (uint32_t)value; }
+    else if (n == "frames_per_launch") { if (value < 1) return bad(); c->frames_per_launch = (unsigned)value; }
+    else if (n == "run_ahead") { if (value < 0 || value > 1) return bad(); c->run_ahead = (uint32_t)value; }
+    else return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_set_option: unknown option " + n);
+    return PRT_OK;
+}
+
+extern "C" const char* prt_kernel_variant(prt_ctx* c) {
+    if (!c) return "";
+    c->variant = std::string(c->last.name) + (c->last.waves ? " waves=" + std::to_string(c->last.waves) + (c->last.scatter ? " pixels=scattered" : " pixels=tiles") : "");
+    return c->variant.c_str();
 }
 
 extern "C" int prt_synchronize(prt_ctx* c) {

@@ -1,246 +1,31 @@
-// pt_kernels.hip -- gfx950 kernels of libprt (see pt_device.h for the arithmetic contract and the lane machine).
+// pt_kernels.hip -- the small kernels of libprt and the dispatch to the render kernel's compiled material sets.
 //
-//   render_kernel<MATS, MEDIUM>   the hot path: one lane = one pixel, n_frames segments per launch
-//   state_to_rtd / rtd_to_state   80 B/px SoA planes <-> the reference's 112 B RTD records
-//   count_kernel                  sum of samples / segments / frozen pixels (Msamples/s accounting)
-//
-// Launch geometry: one wave per workgroup, owning an 8x8 pixel tile (primary rays of one wave walk the same
-// BVH nodes); dynamic LDS (DevScene::stack_levels x 256 B per workgroup) holds the traversal stacks.  A
-// 1920x1080 frame is 32 400 workgroups >> 256 CUs x 16 resident waves, rendered as two interleaved sets of
-// tiles on two streams (prt_api.cpp).
-#include <hip/hip_runtime.h>
-
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-
-#include "pt_device.h"
-#include "pt_launch.h"
+//   render_kernel<MATS, MEDIUM, WAVES>   pt_render.h, instantiated by pt_inst_*.hip (one file per material set: they compile in parallel)
+//   state_to_rtd / rtd_to_state          80 B/px SoA planes <-> the reference's 112 B RTD records
+//   count_kernel                         sum of samples / segments / frozen pixels (Msamples/s accounting)
+//   tonemap_kernel                       shaders/tonemapper.glsl
+//   selftest_*                           per-function known-answer entries
+#include "pt_render.h"
 #include "pt_selftest.h"
 
+#ifdef PT_UNITY            // development builds (tools/build_variant.sh, tools/isa.sh): one translation unit
+#ifdef PT_DEV_ONE_VARIANT
+#include "pt_inst_light_diff.hip"
+#else
+#include "pt_inst_light_diff.hip"
+#include "pt_inst_coat.hip"
+#include "pt_inst_rough_cond.hip"
+#include "pt_inst_rough_diel.hip"
+#include "pt_inst_generic.hip"
+#include "pt_inst_sdf.hip"
+#include "pt_inst_view.hip"
+#include "pt_inst_view_sdf.hip"
+#endif
+#elif defined(PT_PHASE_CLOCKS) || defined(PT_DEV_ONE_VARIANT)
+#error "PT_PHASE_CLOCKS / PT_DEV_ONE_VARIANT builds are unity builds: add -DPT_UNITY"
+#endif
+
 namespace prt {
-
-using namespace dev;
-
-#ifndef PT_WAIT_RATIO
-#define PT_WAIT_RATIO 1u    // a walk phase is cut short only while more than this many lanes wait per lane still walking (0: while
-                            // any lane waits -- the first form of the rule: 1.3 % slower on cornell, the same on the big mesh)
-#endif
-// waves per SIMD the register allocator must leave room for: 6 (80 VGPRs).  The history of this number is the history of the lane's
-// registers: 4 (128 VGPRs) while the SLP vectorizer paired floats into 64-bit registers; 5 (96) without it and with the
-// lane's flags as bit-fields of one word; 6 once fields of different phases shared registers, the cached hit dropped its position
-// and the walk state its spare words -- +1 ... 3 % over 5 on every variant (LIGHT|DIFF: 56 B of scratch at 80 VGPRs, none at 96;
-// generic: 88 B; with a medium 76 ... 120 B), +4 ... 7 % through a tree beyond one XCD's L2.  7 waves the same, 8: -10 %.
-// PRT_WAVES=4 / 5 / 6 forces one build (PT_MIN_WAVES / PT_WAVES / PT_BIG_WAVES).
-#ifndef PT_BIG_WAVES
-#define PT_BIG_WAVES 6
-#endif
-#ifndef PT_WAVES
-#define PT_WAVES 5
-#endif
-#ifndef PT_MIN_WAVES
-#define PT_MIN_WAVES 4
-#endif
-#ifndef PT_UNIFIED
-#define PT_UNIFIED 0        // a lane's box step and its pending triangle test share one load per iteration (0: box steps, then triangle tests)
-#endif
-#define PT_BLOCK 64         // threads per workgroup: ONE wave.  A workgroup's slot (LDS, dispatch) frees only when its last wave
-                            // ends, and waves over the mesh run ~3x longer than waves over a wall: one-wave groups +4 % over 256
-
-// One wave = one 8x8 tile; every lane runs the lane machine of pt_device.h on its pixel until it has done its n_frames
-// segments (or froze).  What is wave-level here is only the SCHEDULE: when the two walk phases of an iteration end.
-//   walk phase rule: go on while at least fa.walk_min_lanes (closest-hit phase) / fa.shadow_min_lanes (any-hit phase) lanes
-//   are still walking; below that, stop as soon as more lanes wait for the phase to end (they finished their walk in it, or
-//   sit in the stage behind it) than walk.  A lane cut off keeps its WalkState and LDS stack and resumes in the same phase
-//   of the next iteration.
-//   run-ahead ("N spp" launches, fa.run_ahead): a lane that has done its n_frames starts on the next launch's frames for as
-//   long as another lane of the wave still owes frames of this one; its lead goes into the state (q4.w >> 2).
-// WAVES = waves per SIMD the register allocator leaves room for.
-#ifdef PT_PHASE_CLOCKS                    // development builds: cycles of a wave per phase of the iteration (tools/phase_clocks.sh)
-__device__ unsigned long long g_phase_clocks[12];    // 0..5, 7 cycles per phase, 6 iterations; 8 most iterations of one wave, 9 longest wave (cycles), 10 waves, 11 idle lane-iterations
-#define PT_CLK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); clk_[k] += now_ - last_; last_ = now_; } while (0)
-#else
-#define PT_CLK(k) do { } while (0)
-#endif
-
-template <unsigned MATS, bool MEDIUM, int WAVES>
-__global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene sc, const DevCamera cam, const DevState S,
-                                                                 const FrameArgs fa, float4* __restrict__ fb) {
-    const int tiles_x = (fa.width + 7) / 8;
-    const int lane = threadIdx.x & 63;
-    // fa.scatter: the wave's 64 pixels come from 64 tiles spread over the launch's share of the frame instead of one 8x8 tile.
-    // Every wave then gets its share of the expensive regions: a launch with few rounds of waves no longer waits for the
-    // tiles over the mesh (512x512: +39 %); a big frame loses the coherence of neighbouring pixels' first segments (-17 %).
-    const unsigned vpix = fa.scatter ? (unsigned)lane * gridDim.x + blockIdx.x : blockIdx.x * 64u + (unsigned)lane;
-    const unsigned tile = (vpix >> 6) * fa.tile_stride + fa.tile_first;
-    const int tl = (int)(vpix & 63u);
-    const int tile_x = (int)(tile % (unsigned)tiles_x), tile_y = (int)(tile / (unsigned)tiles_x);
-    const int lx = tile_x * 8 + (tl & 7);
-    const int ly = tile_y * 8 + (tl >> 3);
-    // a lane outside the frame (edge tiles) idles through the kernel: every wave reaches the end, where the last one reports
-    const bool in_frame = lx < fa.width && ly < fa.rows;
-    const size_t id = in_frame ? (size_t)ly * (size_t)fa.width + (size_t)lx : 0;
-    const int gx = lx;
-    const int gy = fa.row0 + (ly / fa.block_rows * fa.n_parts + fa.part) * fa.block_rows + ly % fa.block_rows;
-
-    Lane L;
-    lane_init(L);
-    if (!in_frame) { L.f = 0xffffffffu; L.reset = true; L.samples = 0xffffffffu; L.wasSpecular = false; }   // owes no frame, starts none
-    else {
-        const float4 a = S.q0[id], b = S.q1[id], c = S.q2[id], d = S.q3[id];
-        const uint4 e = S.q4[id];
-        L.origin = F3(a.x, a.y, a.z); L.t = a.w;                // TempRay.time = ray.t of the last segment (main.cl:28)
-        L.dir = F3(b.x, b.y, b.z); L.time = b.w;                // TempRay.dist = ray.time
-        L.mask = F3(c.x, c.y, c.z); L.total = prt_f2u(c.w);
-        L.acc[0] = d.x; L.acc[1] = d.y; L.acc[2] = d.z; L.acc[3] = d.w;
-        L.samples = e.x;
-        L.diff = e.y & 0xffffu; L.spec = e.y >> 16;
-        L.trans = e.z & 0xffffu; L.scatters = e.z >> 16;
-        L.wasSpecular = (e.w & 1u) != 0; L.reset = (e.w & 2u) != 0;
-        L.f = e.w >> 2;                                         // frames of this launch done in an earlier one (run_ahead)
-    }
-    extern __shared__ unsigned lds_stack[];                     // sc.stack_levels x PT_BLOCK, sized by the launch
-    TravStack stk;
-    stk.lds = lds_stack + threadIdx.x; stk.stride = PT_BLOCK;
-    const unsigned T = fa.walk_min_lanes, TD = fa.shadow_min_lanes, TQ = fa.tri_sixteenths;
-#ifdef PT_PHASE_CLOCKS
-    unsigned long long clk_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_readcyclecounter();
-    const unsigned long long start_ = last_;
-    unsigned long long done_lanes_ = 0;
-#endif
-    for (;;) {
-        const bool runnable = lane_runnable(fa, L, __any(lane_owes_frames(fa, L)));
-        if (!__any(runnable || L.stage != ST_READY)) break;     // every lane has done its frames (or is frozen)
-        PT_CLK(7);
-#ifdef PT_PHASE_CLOCKS
-        done_lanes_ += (unsigned long long)__popcll(__ballot(!runnable && L.stage == ST_READY));
-#endif
-        if (runnable) { PT_WSTAT(4); lane_front<MATS, MEDIUM>(sc, cam, fa, L, gx, gy); }                // A
-        PT_CLK(0);
-        {                                                                                                 // B
-            const bool walking = L.stage == ST_WALKC;
-            const Ray wr = lane_closest_ray<MEDIUM>(L);
-            const RayPre p = ray_pre(wr);
-            if (walking && L.fresh) { walk_begin(sc, false, wr, PT_INF, p, L.w, stk); L.fresh = false; }
-            const bool go = walking && !L.w.done;
-            const unsigned n_start = (unsigned)__popcll(__ballot(go));
-            const unsigned n_other = (unsigned)__popcll(__ballot((walking && L.w.done) || L.stage == ST_BACK));
-            if (go) {
-#if PT_UNIFIED
-                // every iteration a lane takes ONE unit of its walk (the box half of a step, or one pending triangle) behind one
-                // load; the lanes with a triangle pending sit iterations out until enough of the phase's lanes have one (the first
-                // iteration of a phase takes them anyway: a pending lane tests at least one triangle per iteration of the wave)
-                for (bool first = true;; first = false) {
-                    const bool pending = L.w.pend_count != 0u;
-                    const unsigned n_in = (unsigned)__popcll(__ballot(1)), n_pend = (unsigned)__popcll(__ballot(pending));
-                    if (!pending || first || n_pend * 16u >= n_in * TQ) walk_unit(sc, false, wr, p, L.w, stk);
-                    if (L.w.done) break;
-                    const unsigned n_act = (unsigned)__popcll(__ballot(1));
-                    if (n_act < T && n_other + (n_start - n_act) > PT_WAIT_RATIO * n_act) break;   // the lanes that wait outnumber the walkers
-                }
-#else
-                for (;;) {
-                    if (!L.w.pend_count) walk_box(sc, false, wr, p, L.w, stk);
-                    // the triangles that the box steps found are tested once enough of the walking lanes have one pending (or the
-                    // phase is about to end: a pending lane tests at least one per iteration of the wave)
-                    const bool pending = L.w.pend_count != 0u;
-                    const unsigned n_in = (unsigned)__popcll(__ballot(1)), n_pend = (unsigned)__popcll(__ballot(pending));
-                    const unsigned n_act = (unsigned)__popcll(__ballot(!L.w.done));
-                    const bool cut = n_act < T && n_other + (n_start - n_act) > PT_WAIT_RATIO * n_act;   // the lanes that wait outnumber the walkers
-                    if (pending && (n_pend * 16u >= n_in * TQ || cut)) walk_tri(sc, false, wr, L.w);
-                    if (L.w.done || cut) break;
-                }
-#endif
-            }
-            PT_CLK(1);
-            if (walking && L.w.done) { PT_WSTAT(5); lane_closest_done<MATS, MEDIUM>(sc, L); }
-            PT_CLK(2);
-        }
-        if (L.stage == ST_BACK) { PT_WSTAT(6); lane_back<MATS, MEDIUM>(sc, L); }                         // C
-        PT_CLK(3);
-        {                                                                                                 // D
-            const bool walking = L.stage == ST_WALKS;
-            const Ray wr = lane_shadow_ray<MEDIUM>(L);
-            const RayPre p = ray_pre(wr);
-            if (walking && L.fresh) { walk_begin(sc, true, wr, wr.t, p, L.w, stk); L.fresh = false; }
-            const bool go = walking && !L.w.done;
-            const unsigned n_start = (unsigned)__popcll(__ballot(go));
-            const unsigned n_other = (unsigned)__popcll(__ballot((walking && L.w.done) || L.stage == ST_FINISH));
-            if (go) {
-#if PT_UNIFIED
-                // every iteration a lane takes ONE unit of its walk (the box half of a step, or one pending triangle) behind one
-                // load; the lanes with a triangle pending sit iterations out until enough of the phase's lanes have one (the first
-                // iteration of a phase takes them anyway: a pending lane tests at least one triangle per iteration of the wave)
-                for (bool first = true;; first = false) {
-                    const bool pending = L.w.pend_count != 0u;
-                    const unsigned n_in = (unsigned)__popcll(__ballot(1)), n_pend = (unsigned)__popcll(__ballot(pending));
-                    if (!pending || first || n_pend * 16u >= n_in * TQ) walk_unit(sc, true, wr, p, L.w, stk);
-                    if (L.w.done) break;
-                    const unsigned n_act = (unsigned)__popcll(__ballot(1));
-                    if (n_act < TD && n_other + (n_start - n_act) > PT_WAIT_RATIO * n_act) break;   // the lanes that wait outnumber the walkers
-                }
-#else
-                for (;;) {
-                    if (!L.w.pend_count) walk_box(sc, true, wr, p, L.w, stk);
-                    const bool pending = L.w.pend_count != 0u;
-                    const unsigned n_in = (unsigned)__popcll(__ballot(1)), n_pend = (unsigned)__popcll(__ballot(pending));
-                    const unsigned n_act = (unsigned)__popcll(__ballot(!L.w.done));
-                    const bool cut = n_act < TD && n_other + (n_start - n_act) > PT_WAIT_RATIO * n_act;
-                    if (pending && (n_pend * 16u >= n_in * TQ || cut)) walk_tri(sc, true, wr, L.w);
-                    if (L.w.done || cut) break;
-                }
-#endif
-            }
-            if (walking && L.w.done) { L.occluded = L.w.found; L.stage = ST_FINISH; }
-        }
-        PT_CLK(4);
-        if (L.stage == ST_FINISH) { PT_WSTAT(7); lane_finish<MATS, MEDIUM>(sc, L); }                           // E
-        PT_CLK(5);
-#ifdef PT_PHASE_CLOCKS
-        ++clk_[6];
-#endif
-    }
-#ifdef PT_PHASE_CLOCKS
-    if (lane == (int)__builtin_ctzll(__ballot(1))) {
-        for (int k = 0; k < 8; ++k) atomicAdd(&g_phase_clocks[k], clk_[k]);
-        atomicMax(&g_phase_clocks[8], clk_[6]);
-        atomicMax(&g_phase_clocks[9], last_ - start_);
-        atomicAdd(&g_phase_clocks[10], 1ull);
-        atomicAdd(&g_phase_clocks[11], done_lanes_);
-    }
-#endif
-    if (in_frame && L.f) {
-        // frames of the NEXT launch already done (run_ahead); a frozen pixel owes nothing and is ahead of nothing
-        const bool frozen = fa.spp_limit && L.reset && L.samples >= fa.spp_limit;
-        const unsigned frames_ahead = (!frozen && L.f > fa.n_frames) ? L.f - fa.n_frames : 0u;
-        S.q0[id] = make_float4(L.origin.x, L.origin.y, L.origin.z, L.t);
-        S.q1[id] = make_float4(L.dir.x, L.dir.y, L.dir.z, L.time);
-        S.q2[id] = make_float4(L.mask.x, L.mask.y, L.mask.z, prt_u2f(L.total));
-        S.q3[id] = make_float4(L.acc[0], L.acc[1], L.acc[2], L.acc[3]);
-        S.q4[id] = make_uint4(L.samples, (L.diff & 0xffffu) | (L.spec << 16), (L.trans & 0xffffu) | (L.scatters << 16),
-                              (L.wasSpecular ? 1u : 0u) | (L.reset ? 2u : 0u) | (frames_ahead << 2));
-        const float ns = (MATS & PT_MATS_VIEW) ? 1.0f : (float)L.samples;      // write_imagef, main.cl:159 (a debug view: :161)
-        fb[id] = make_float4(L.acc[0] / ns, L.acc[1] / ns, L.acc[2] / ns, L.acc[3] / ns);
-    }
-    if (fa.unfinished) {
-        const bool unfinished = in_frame && !(fa.spp_limit && L.reset && L.samples >= fa.spp_limit);
-        const unsigned long long m = __ballot(unfinished);
-        if (lane == (int)__builtin_ctzll(__ballot(1))) {
-            // returning atomic: its value is back only once the add has been performed at the device's coherence point
-            const unsigned long long before = m ? atomicAdd(fa.unfinished, (unsigned long long)__popcll(m)) : 0ull;
-            if (fa.unfinished_host && before != ~0ull) {       // (never equal: the test orders the ticket behind the add without a
-                // fence -- a device-scope fence writes back and invalidates this XCD's L2, 2.5 % when every wave does it)
-                // The last wave of the launch hands the total to the host and leaves the counters clean for the next launch
-                // (no wave returns early, so every wave of the grid gets here).
-                if (atomicAdd(fa.unfinished + 1, 1ull) == (unsigned long long)gridDim.x - 1ull) {
-                    const unsigned long long total = atomicExch(fa.unfinished, 0ull);
-                    atomicExch(fa.unfinished + 1, 0ull);
-                    *reinterpret_cast<volatile unsigned long long*>(fa.unfinished_host) = total;   // visible to the host at kernel end
-                }
-            }
-        }
-    }
-}
 
 __global__ void state_to_rtd(const DevState S, prt_path_state* __restrict__ out, size_t n) {
     const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -392,60 +177,6 @@ __global__ void selftest_fn_kernel(int fn, const float* __restrict__ params, con
     for (int k = 0; k < 32; ++k) out[32 * (size_t)i + k] = y[k];
 }
 
-// ---- host-side launchers -------------------------------------------------------------------------------
-// tiles (= waves) of this launch, and whether its pixels are scattered over them (render_kernel): on when the launch has few rounds
-// of waves -- up to 6 144 tiles, or 24 576 through a tree beyond one XCD's L2, whose expensive tiles are more expensive (1080p: +14 %,
-// 3840x2160: -4 %)
-static unsigned launch_grid(const DevScene& sc, const FrameArgs& fa, bool& scatter) {
-    const unsigned tiles_x = ((unsigned)fa.width + 7u) / 8u, tiles_y = ((unsigned)fa.rows + 7u) / 8u;
-    const unsigned n_tiles = tiles_x * tiles_y;
-    const unsigned grid = fa.tile_first >= n_tiles ? 0u : (n_tiles - fa.tile_first + fa.tile_stride - 1) / fa.tile_stride;   // tiles of this sub-part
-    static const int forced_scatter = [] { const char* e = std::getenv("PRT_SCATTER"); return e ? std::atoi(e) : -1; }();
-    scatter = forced_scatter >= 0 ? forced_scatter != 0 : grid <= (sc.n_pairs > 65536u ? 24576u : 6144u);
-    return grid;
-}
-template <unsigned MATS, bool MEDIUM, int WAVES>
-static void launch_variant_w(const DevScene& sc, const DevCamera& cam, const DevState& S, const FrameArgs& fa, float4* fb,
-                             hipStream_t stream, unsigned grid, bool scatter) {
-    const size_t lds = (size_t)sc.stack_levels * PT_BLOCK * sizeof(unsigned);
-    static size_t lds_attr = 0;                                  // per template instance
-    if (lds > 65536u && lds > lds_attr) {   // only a tree that fills the reference's 64-entry stack to the brim
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<MATS, MEDIUM, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        lds_attr = lds;
-    }
-    if (!grid) return;
-    FrameArgs fb_args = fa;
-    fb_args.scatter = scatter ? 1u : 0u;
-    // walk phases end below this many walking lanes (0 = not set by the caller): 8; 6 with a medium (8: -1 %) and for scattered
-    // pixels, whose waves hold more deep walks (512x512 coat: 6 +4 %).  Shadow rays: in a small tree 99 % end at the root and the
-    // rest is shallow -- cutting one off costs its pixel a whole iteration, letting the wave finish them costs a few steps (cornell
-    // +3 %); through a big mesh they are as deep as any ray and the bound pays as it does for the closest-hit walks (+14 %).
-    // Through a tree beyond one XCD's L2: 12 (3840x2160: 8 -> 2.46, 12 -> 2.52, 16 -> 2.51 G segments/s).
-    if (!fb_args.walk_min_lanes) fb_args.walk_min_lanes = sc.n_pairs > 65536u ? 12u : ((MEDIUM || scatter) ? 6u : 8u);
-    if (!fb_args.shadow_min_lanes) fb_args.shadow_min_lanes = sc.n_pairs > 65536u ? fb_args.walk_min_lanes : 1u;
-    hipLaunchKernelGGL((render_kernel<MATS, MEDIUM, WAVES>), dim3(grid), dim3(PT_BLOCK), lds, stream, sc, cam, S, fb_args, fb);
-}
-template <unsigned MATS, bool MEDIUM>
-static void launch_variant(const DevScene& sc, const DevCamera& cam, const DevState& S, const FrameArgs& fa, float4* fb,
-                           hipStream_t stream) {
-    static const int forced = [] { const char* e = std::getenv("PRT_WAVES"); return e ? std::atoi(e) : 0; }();   // 4 / 5 / 6: override (tests, experiments)
-    bool scatter;
-    const unsigned grid = launch_grid(sc, fa, scatter);
-    // 6 waves per SIMD; 5 where a launch of a small tree is one or two rounds of waves (scattered pixels): every wave then runs at its
-    // own latency and the spills of the 80-register build cost more than the sixth wave hides (512x512 coat: 5 +5 %)
-    const int waves = forced ? forced : ((scatter && sc.n_pairs <= 65536u) ? PT_WAVES : PT_BIG_WAVES);
-#ifdef PT_DEV_ONE_VARIANT
-    (void)waves;
-    launch_variant_w<MATS, MEDIUM, PT_BIG_WAVES>(sc, cam, S, fa, fb, stream, grid, scatter);
-#else
-    if (waves >= PT_BIG_WAVES) launch_variant_w<MATS, MEDIUM, PT_BIG_WAVES>(sc, cam, S, fa, fb, stream, grid, scatter);
-    else if (waves <= PT_MIN_WAVES) launch_variant_w<MATS, MEDIUM, PT_MIN_WAVES>(sc, cam, S, fa, fb, stream, grid, scatter);
-    else launch_variant_w<MATS, MEDIUM, PT_WAVES>(sc, cam, S, fa, fb, stream, grid, scatter);
-#endif
-}
-
-// Variant choice = the AOT analogue of the reference's per-scene program build (include/CL/cl_kernel.h):
-// material set (LIGHT|DIFF only, or generic) x global medium.
 #ifdef PT_PHASE_CLOCKS
 void dump_phase_clocks() {
     unsigned long long h[12] = {0};
@@ -472,41 +203,27 @@ void dump_phase_clocks() {
 }
 #endif
 
-const char* launch_render(const DevScene& sc, const DevCamera& cam, const DevState& S, const FrameArgs& fa, float4* fb,
-                          hipStream_t stream) {
-    constexpr unsigned LD = PRT_MAT_LIGHT | PRT_MAT_DIFF;
+// Variant choice = the AOT analogue of the reference's per-scene program build (include/CL/cl_kernel.h:226-345 compiles exactly the
+// scene's ACTIVE_MATS): the material sets of the BASELINE configs are compiled (LIGHT|DIFF, +COAT, +ROUGH_COND, +DIEL|ROUGH_DIEL),
+// any other set runs the generic variant, which dispatches on the material's type bits at run time -- the same code, the same bits
+// (LaunchOpts::generic forces it: the tests run every golden through both).
+RenderLaunch launch_render(const DevScene& sc, const DevCamera& cam, const DevState& S, const FrameArgs& fa, float4* fb,
+                           hipStream_t stream, const LaunchOpts& lo) {
     const unsigned am = sc.active_mats;
+    const bool medium = sc.has_medium != 0;
 #ifdef PT_DEV_ONE_VARIANT                 // development builds (tools/): only the headline variant, compiles in seconds
-    if (sc.n_sdfs || sc.has_medium || am != LD) return nullptr;
-    launch_variant<LD, false>(sc, cam, S, fa, fb, stream);
-    return "render_kernel<LIGHT|DIFF>";
+    if (sc.n_sdfs || medium || sc.view || am != (PRT_MAT_LIGHT | PRT_MAT_DIFF)) return RenderLaunch{};
+    return launch_set_light_diff(false, sc, cam, S, fa, fb, stream, lo);
 #else
-    if (sc.view) {                        // the debug views: generic material set, the default wave count only
-        constexpr unsigned V = PT_MATS_VIEW, VS = PT_MATS_VIEW | PT_MATS_SDF;
-        bool vscatter;
-        const unsigned vgrid = launch_grid(sc, fa, vscatter);
-        if (sc.n_sdfs) {
-            if (!sc.has_medium) launch_variant_w<VS, false, PT_BIG_WAVES>(sc, cam, S, fa, fb, stream, vgrid, vscatter);
-            else launch_variant_w<VS, true, PT_BIG_WAVES>(sc, cam, S, fa, fb, stream, vgrid, vscatter);
-        } else {
-            if (!sc.has_medium) launch_variant_w<V, false, PT_BIG_WAVES>(sc, cam, S, fa, fb, stream, vgrid, vscatter);
-            else launch_variant_w<V, true, PT_BIG_WAVES>(sc, cam, S, fa, fb, stream, vgrid, vscatter);
-        }
-        return "render_kernel<generic,view>";
+    if (sc.view) return sc.n_sdfs ? launch_set_view_sdf(medium, sc, cam, S, fa, fb, stream, lo) : launch_set_view(medium, sc, cam, S, fa, fb, stream, lo);
+    if (sc.n_sdfs) return launch_set_sdf(medium, sc, cam, S, fa, fb, stream, lo);      // H_SDF scenes: the generic set with the raymarcher
+    if (!lo.generic) {
+        if (am == (PRT_MAT_LIGHT | PRT_MAT_DIFF)) return launch_set_light_diff(medium, sc, cam, S, fa, fb, stream, lo);
+        if (am == (PRT_MAT_LIGHT | PRT_MAT_DIFF | PRT_MAT_COAT)) return launch_set_coat(medium, sc, cam, S, fa, fb, stream, lo);
+        if (am == (PRT_MAT_LIGHT | PRT_MAT_DIFF | PRT_MAT_ROUGH_COND)) return launch_set_rough_cond(medium, sc, cam, S, fa, fb, stream, lo);
+        if (am == (PRT_MAT_LIGHT | PRT_MAT_DIFF | PRT_MAT_DIEL | PRT_MAT_ROUGH_DIEL)) return launch_set_rough_diel(medium, sc, cam, S, fa, fb, stream, lo);
     }
-    if (sc.n_sdfs) {                      // H_SDF scenes: the generic variants that carry the raymarcher
-        if (!sc.has_medium) { launch_variant<PT_MATS_SDF, false>(sc, cam, S, fa, fb, stream); return "render_kernel<generic,sdf>"; }
-        launch_variant<PT_MATS_SDF, true>(sc, cam, S, fa, fb, stream);
-        return "render_kernel<generic,sdf,medium>";
-    }
-    if (!sc.has_medium) {
-        if (am == LD) { launch_variant<LD, false>(sc, cam, S, fa, fb, stream); return "render_kernel<LIGHT|DIFF>"; }
-        launch_variant<0u, false>(sc, cam, S, fa, fb, stream);
-        return "render_kernel<generic>";
-    }
-    if (am == LD) { launch_variant<LD, true>(sc, cam, S, fa, fb, stream); return "render_kernel<LIGHT|DIFF,medium>"; }
-    launch_variant<0u, true>(sc, cam, S, fa, fb, stream);
-    return "render_kernel<generic,medium>";
+    return launch_set_generic(medium, sc, cam, S, fa, fb, stream, lo);
 #endif
 }
 

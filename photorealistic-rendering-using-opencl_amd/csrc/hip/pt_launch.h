@@ -7,10 +7,30 @@
 
 namespace prt {
 
+// launcher-level choices of a context (prt_set_option / PRT_WAVES, PRT_SCATTER, PRT_GENERIC): what is forced, for tests and experiments
+struct LaunchOpts {
+    int waves = 0;          // 0: chosen per launch; 5 / 6: that build of the kernel (waves per SIMD the register allocator leaves room for)
+    int scatter = -1;       // -1: chosen per launch; 0: one 8x8 tile per wave; 1: a wave's pixels scattered over the launch's tiles
+    int generic = 0;        // 1: the run-time-dispatched material set even where the scene's own set is compiled
+};
+// what a launch ran: kernel variant, wave-count build, pixel-to-wave mapping (prt_kernel_variant)
+struct RenderLaunch { const char* name = ""; int waves = 0; int scatter = 0; };
+
 // launches the scene-specialised variant (the AOT analogue of the reference's per-scene program
-// build, include/CL/cl_kernel.h); returns the variant's name for profiles/stats
-const char* launch_render(const DevScene& sc, const DevCamera& cam, const DevState& S, const FrameArgs& fa, float4* fb,
-                          hipStream_t stream);
+// build, include/CL/cl_kernel.h:226-345)
+RenderLaunch launch_render(const DevScene& sc, const DevCamera& cam, const DevState& S, const FrameArgs& fa, float4* fb,
+                           hipStream_t stream, const LaunchOpts& lo);
+// one per compile-time material set (pt_inst_*.hip; each covers medium off / on)
+#define PT_DECLARE_SET(fn) RenderLaunch fn(bool medium, const DevScene& sc, const DevCamera& cam, const DevState& S, const FrameArgs& fa, float4* fb, \
+                                           hipStream_t stream, const LaunchOpts& lo)
+PT_DECLARE_SET(launch_set_light_diff);
+PT_DECLARE_SET(launch_set_coat);
+PT_DECLARE_SET(launch_set_rough_cond);
+PT_DECLARE_SET(launch_set_rough_diel);
+PT_DECLARE_SET(launch_set_generic);
+PT_DECLARE_SET(launch_set_sdf);
+PT_DECLARE_SET(launch_set_view);
+PT_DECLARE_SET(launch_set_view_sdf);
 // workgroups (tiles) launch_render uses for a width x rows frame part
 unsigned render_tile_count(int width, int rows);
 #ifdef PT_PHASE_CLOCKS

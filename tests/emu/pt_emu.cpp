@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -181,6 +182,8 @@ extern "C" int emu_render(const prt_config* cfg, const prt_scene_desc* desc, con
     fa.walk_min_lanes = walk_min_lanes ? walk_min_lanes : 8;
     fa.tri_sixteenths = 4;
     constexpr unsigned LD = PRT_MAT_LIGHT | PRT_MAT_DIFF;
+    const char* e_generic = std::getenv("PT_EMU_GENERIC");
+    const bool generic = e_generic && e_generic[0] == '1';
     std::vector<unsigned> stack_mem;
     const int tiles_x = (width + 7) / 8, tiles_y = (rows + 7) / 8;
     for (int ty = 0; ty < tiles_y; ++ty)
@@ -199,10 +202,16 @@ extern "C" int emu_render(const prt_config* cfg, const prt_scene_desc* desc, con
                 if (!sc.has_medium) run_tile<PT_MATS_SDF, false>(sc, cam, fa, tx, ty, state, out_rgba, sched_seed, stack_mem, ahead);
                 else run_tile<PT_MATS_SDF, true>(sc, cam, fa, tx, ty, state, out_rgba, sched_seed, stack_mem, ahead);
             } else if (!sc.has_medium) {
-                if (sc.active_mats == LD) run_tile<LD, false>(sc, cam, fa, tx, ty, state, out_rgba, sched_seed, stack_mem, ahead);
+                // the compiled material sets of launch_render (pt_kernels.hip); PT_EMU_GENERIC=1: the run-time dispatch instead
+                constexpr unsigned CO = LD | PRT_MAT_COAT, RC = LD | PRT_MAT_ROUGH_COND, RD = LD | PRT_MAT_DIEL | PRT_MAT_ROUGH_DIEL;
+                const unsigned am = generic ? 0u : sc.active_mats;
+                if (am == LD) run_tile<LD, false>(sc, cam, fa, tx, ty, state, out_rgba, sched_seed, stack_mem, ahead);
+                else if (am == CO) run_tile<CO, false>(sc, cam, fa, tx, ty, state, out_rgba, sched_seed, stack_mem, ahead);
+                else if (am == RC) run_tile<RC, false>(sc, cam, fa, tx, ty, state, out_rgba, sched_seed, stack_mem, ahead);
+                else if (am == RD) run_tile<RD, false>(sc, cam, fa, tx, ty, state, out_rgba, sched_seed, stack_mem, ahead);
                 else run_tile<0u, false>(sc, cam, fa, tx, ty, state, out_rgba, sched_seed, stack_mem, ahead);
             } else {
-                if (sc.active_mats == LD) run_tile<LD, true>(sc, cam, fa, tx, ty, state, out_rgba, sched_seed, stack_mem, ahead);
+                if (!generic && sc.active_mats == LD) run_tile<LD, true>(sc, cam, fa, tx, ty, state, out_rgba, sched_seed, stack_mem, ahead);
                 else run_tile<0u, true>(sc, cam, fa, tx, ty, state, out_rgba, sched_seed, stack_mem, ahead);
             }
         }

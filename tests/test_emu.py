@@ -48,6 +48,18 @@ def test_device_code_on_host_matches_reference_golden(prt, oracle, emu, variant,
     _same(oracle, gstate, g["image"], state, img, "%s schedule %s" % (variant, sched))
 
 
+@pytest.mark.parametrize("variant", ["cornell_diffuse", "cornell_coat", "cornell_roughcond", "cornell_roughdiel", "cornell_media"])
+def test_generic_material_dispatch_on_host_matches_reference_golden(prt, oracle, emu, variant, monkeypatch):
+    """scenes whose ACTIVE_MATS is one of the compiled sets, through the run-time dispatch instead (LaunchOpts::generic)"""
+    monkeypatch.setenv("PT_EMU_GENERIC", "1")
+    g = np.load(os.path.join(GOLDEN, variant + ".npz"))
+    W, H, frames = int(g["width"]), int(g["height"]), int(g["frames"])
+    scene, cfg, cam, env = _scene(prt, variant, W, H)
+    state, img = emu.render(oracle.PATH_STATE_DTYPE, cfg, scene.desc, cam, W, H, prt.seed_pairs(frames), env=env, sched_seed=4711)
+    gstate = np.ascontiguousarray(g["state"]).view(oracle.PATH_STATE_DTYPE).reshape(-1)
+    _same(oracle, gstate, g["image"], state, img, "%s generic set" % variant)
+
+
 @pytest.mark.parametrize("fixture", list(VIEW_VARIANTS))
 def test_debug_views_on_host_match_reference_golden(prt, oracle, emu, fixture):
     """the PT_MATS_VIEW kernel variants (prt_config::view_option = VIEW_NORMAL / VIEW_BVH_HIT) under a random schedule; plus an SDF

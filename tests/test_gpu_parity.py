@@ -414,45 +414,83 @@ def test_debug_views_match_reference_golden(prt, oracle, fixture):
         rb.close()
 
 
-@pytest.mark.parametrize("scatter", ["0", "1"])
-def test_pixel_to_wave_mappings_match_golden(prt, oracle, scatter, monkeypatch):
-    """a wave renders one 8x8 tile, or (launches with few rounds of waves) 64 pixels of 64 tiles spread over the launch: both
-    mappings forced here, on a ragged frame in interleaved row blocks (edge tiles: lanes outside the frame idle) and in spp mode"""
-    monkeypatch.setenv("PRT_SCATTER", scatter)
-    variant = "cornell_mixed"
+def _golden_through(prt, oracle, variant, what, **options):
+    """renders a golden's inputs under the given prt_set_option choices; returns what the launches ran"""
     g = np.load(os.path.join(GOLDEN, variant + ".npz"))
     W, H, frames = int(g["width"]), int(g["height"]), int(g["frames"])
     scene, cfg, cam, env, r = _setup(prt, variant, W, H)
+    for k, v in options.items():
+        r.set_option(k, v)
     r.render_frames(prt.seed_pairs(frames))
     gstate = np.ascontiguousarray(g["state"]).view(oracle.PATH_STATE_DTYPE).reshape(-1)
-    _assert_same(oracle, gstate, g["image"], r.read_state(), r.read_framebuffer(), "scatter=%s vs golden" % scatter)
+    _assert_same(oracle, gstate, g["image"], r.read_state(), r.read_framebuffer(), "%s %s vs golden" % (variant, what))
+    ran = r.kernel_variant()
     r.close()
+    return ran
+
+
+@pytest.mark.parametrize("scatter", [0, 1])
+def test_pixel_to_wave_mappings_match_golden(prt, oracle, scatter):
+    """a wave renders one 8x8 tile, or (launches with few rounds of waves) 64 pixels of 64 tiles spread over the launch: both
+    mappings forced here (prt_set_option; what ran is read back), on a ragged frame (edge tiles: lanes outside the frame idle)
+    and in spp mode"""
+    mapping = "pixels=scattered" if scatter else "pixels=tiles"
+    for variant in ("cornell_mixed", "cornell_sdf"):
+        assert mapping in _golden_through(prt, oracle, variant, mapping, scatter=scatter)
+    variant = "cornell_mixed"
     W2, H2, frames2 = 61, 43, 20                                  # neither a multiple of 8
     scene, cfg, cam2, env, r = _setup(prt, variant, W2, H2)
+    r.set_option("scatter", scatter)
     seeds = prt.seed_pairs(frames2)
     ostate, oimg = oracle.Restatement().render(cfg, scene.desc, cam2, W2, H2, seeds, env=env)
     r.render_frames(seeds)
-    _assert_same(oracle, ostate, oimg, r.read_state(), r.read_framebuffer(), "scatter=%s ragged frame" % scatter)
+    assert mapping in r.kernel_variant()
+    _assert_same(oracle, ostate, oimg, r.read_state(), r.read_framebuffer(), "%s ragged frame" % mapping)
     r.close()
     gs = np.load(os.path.join(GOLDEN, "cornell_diffuse_spp.npz"))
     scene, cfg, cam, env, r = _setup(prt, "cornell_diffuse", int(gs["width"]), int(gs["height"]))
+    r.set_option("scatter", scatter)
     r.render_spp(int(gs["spp"]), prt.seed_pairs(int(gs["frames"])))
+    assert mapping in r.kernel_variant()
     sstate = np.ascontiguousarray(gs["state"]).view(oracle.PATH_STATE_DTYPE).reshape(-1)
-    _assert_same(oracle, sstate, gs["image"], r.read_state(), r.read_framebuffer(), "scatter=%s spp golden" % scatter)
+    _assert_same(oracle, sstate, gs["image"], r.read_state(), r.read_framebuffer(), "%s spp golden" % mapping)
     r.close()
 
 
-@pytest.mark.parametrize("waves", ["4", "5"])
-@pytest.mark.parametrize("variant", ["cornell_diffuse", "cornell_media_hg", "cornell_sdf", "cornell_mixed"])
-def test_other_wave_count_builds_match_golden(prt, oracle, variant, waves, monkeypatch):
-    """every kernel variant is built for 4, 5 and 6 waves per SIMD (128 / 96 / 80 registers): 6 is the default, the others forced here"""
-    monkeypatch.setenv("PRT_WAVES", waves)
-    g = np.load(os.path.join(GOLDEN, variant + ".npz"))
-    W, H, frames = int(g["width"]), int(g["height"]), int(g["frames"])
-    scene, cfg, cam, env, r = _setup(prt, variant, W, H)
-    r.render_frames(prt.seed_pairs(frames))
-    gstate = np.ascontiguousarray(g["state"]).view(oracle.PATH_STATE_DTYPE).reshape(-1)
-    _assert_same(oracle, gstate, g["image"], r.read_state(), r.read_framebuffer(), variant + " %s-wave build vs golden" % waves)
+@pytest.mark.parametrize("waves", [5, 6])
+@pytest.mark.parametrize("scatter", [0, 1])
+@pytest.mark.parametrize("variant", ["cornell_diffuse", "cornell_media_hg", "cornell_sdf", "cornell_mixed", "cornell_coat", "cornell_roughdiel"])
+def test_wave_count_builds_match_golden(prt, oracle, variant, waves, scatter):
+    """every kernel variant is built for 5 and 6 waves per SIMD (96 / 80 registers); the launcher picks one per launch (6 in
+    launches of whole tiles, 5 in small launches with scattered pixels).  Both builds x both pixel mappings, forced and read back"""
+    ran = _golden_through(prt, oracle, variant, "waves=%d scatter=%d" % (waves, scatter), waves=waves, scatter=scatter)
+    assert "waves=%d" % waves in ran and ("pixels=scattered" if scatter else "pixels=tiles") in ran, ran
+
+
+COMPILED_SETS = {"cornell_diffuse": "<LIGHT|DIFF>", "cornell_media": "<LIGHT|DIFF,medium>", "cornell_coat": "<LIGHT|DIFF|COAT>",
+                 "cornell_quadlight": "<LIGHT|DIFF|COAT>", "cornell_roughcond": "<LIGHT|DIFF|ROUGH_COND>",
+                 "cornell_roughdiel": "<LIGHT|DIFF|DIEL|ROUGH_DIEL>"}
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS))
+def test_compiled_material_sets_and_generic_dispatch_match_golden(prt, oracle, variant):
+    """the reference compiles exactly the scene's ACTIVE_MATS (include/CL/cl_kernel.h:226-345); here the sets of the BASELINE
+    configs are compiled and every other scene runs the variant that dispatches at run time.  Every golden goes through the
+    instance the launcher picks AND through the generic one (prt_set_option "generic"); what ran is read back."""
+    picked = _golden_through(prt, oracle, variant, "scene's own set")
+    if variant in COMPILED_SETS:
+        assert COMPILED_SETS[variant] in picked, picked
+    forced = _golden_through(prt, oracle, variant, "generic set", generic=1)
+    assert "generic" in forced, forced
+
+
+def test_options_are_validated(prt):
+    scene = prt.HostScene("cornell_diffuse.json")
+    r = prt.Renderer(scene.config(), device=0)
+    assert r.kernel_variant() == ""
+    for name, value in (("waves", 4), ("waves", 7), ("scatter", 2), ("generic", 2), ("tri_q", 17), ("frames_per_launch", 0), ("no_such_option", 1)):
+        with pytest.raises(prt.PrtError):
+            r.set_option(name, value)
     r.close()
 
 

@@ -5,7 +5,7 @@ set -e
 name=$1; shift
 P="$(cd "$(dirname "$0")/.." && pwd)/photorealistic-rendering-using-opencl_amd"
 O=/tmp/prt_variant_$name; mkdir -p $O $P/variants
-COMMON="-std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -I$P/../include -I$P/csrc/host -I$P/csrc/hip"
+COMMON="-std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -DPT_UNITY -I$P/../include -I$P/csrc/host -I$P/csrc/hip"
 for s in prt_api.cpp pt_pack.cpp pt_kernels.hip; do
   /opt/rocm/bin/hipcc $COMMON -x hip --offload-arch=gfx950 "$@" -c $P/csrc/hip/$s -o $O/$s.o &
 done
