@@ -37,6 +37,39 @@ namespace dev {
 #endif
 #define PT_HD __host__ __device__ __forceinline__      // the few helpers the host shares (camera basis)
 
+// 1/x, correctly rounded (= prt_recip, the IEEE divide the CPU side does), in 6 vector instructions instead of the
+// 11 of the compiler's divide expansion: hardware estimate + one fma Newton step is exact whenever neither x nor
+// 1/x is subnormal (checked over all 2^32 inputs by prt_selftest_math fn 17, tests/test_gpu_parity.py); the rest
+// (zero, subnormal, huge, inf, nan) takes the divide.
+#ifndef PT_RECIP_STEPS
+#define PT_RECIP_STEPS 1
+#endif
+PT_HD float hw_recip(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned e = (prt_f2u(x) >> 23) & 0xffu;
+    if (e - 2u < 251u) {                                        // 2^-125 <= |x| < 2^126
+        float r = __builtin_amdgcn_rcpf(x);
+        for (int k = 0; k < PT_RECIP_STEPS; ++k) r = __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+        return r;
+    }
+#endif
+    return 1.0f / x;
+}
+// sqrt(x), correctly rounded (= prt_sqrt, the IEEE square root the CPU side computes), without the 17 vector instructions of the
+// compiler's expansion (scaling for subnormals, two neighbour tests, class fix-up): hardware estimate of 1/sqrt(x), s0 = x * r and one
+// fma correction step s0 + (x - s0 * s0) * r / 2 in the range where none of it needs care (5 instructions + the range test); everything else takes the IEEE one.  Checked over all 2^32 inputs by prt_selftest_math
+// fn 19 (tests/test_gpu_parity.py).
+PT_HD float hw_sqrt(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned e = (prt_f2u(x) >> 23) & 0x1ffu;              // sign and exponent
+    if (e - 27u < 200u) {                                        // positive, 2^-100 <= x < 2^100
+        const float r = __builtin_amdgcn_rsqf(x);
+        const float s0 = x * r, hh = 0.5f * r;
+        return __builtin_fmaf(__builtin_fmaf(-s0, s0, x), hh, s0);
+    }
+#endif
+    return __builtin_sqrtf(x);
+}
 struct f3 { float x, y, z; };
 PT_HD f3 F3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
 PT_HD f3 splat(float s) { return F3(s, s, s); }
@@ -48,8 +81,8 @@ PT_HD f3 operator/(f3 a, float s) { return F3(a.x / s, a.y / s, a.z / s); }
 PT_HD f3 operator-(f3 a) { return F3(-a.x, -a.y, -a.z); }
 PT_HD float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 PT_HD f3 cross(f3 a, f3 b) { return F3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
-PT_HD float length(f3 a) { return prt_sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
-PT_HD f3 normalize(f3 a) { float inv = 1.0f / prt_sqrt(a.x * a.x + a.y * a.y + a.z * a.z); return F3(a.x * inv, a.y * inv, a.z * inv); }
+PT_HD float length(f3 a) { return hw_sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+PT_HD f3 normalize(f3 a) { float inv = hw_recip(hw_sqrt(a.x * a.x + a.y * a.y + a.z * a.z)); return F3(a.x * inv, a.y * inv, a.z * inv); }
 PT_HD f3 ld3(const float* p) { return F3(p[0], p[1], p[2]); }
 PT_DEV f3 vexp(f3 a) { return F3(prt_exp(a.x), prt_exp(a.y), prt_exp(a.z)); }
 PT_DEV float fmax3(f3 v) { return prt_fmax(prt_fmax(v.x, v.y), v.z); }
@@ -58,24 +91,6 @@ PT_DEV float avg3(f3 v) { return (v.x * 1.0f + v.y * 1.0f + v.z * 1.0f) * 0.3333
 // min/max for the slab test only.  The operands there are compared with <=, > afterwards, so the
 // sign of a zero result is irrelevant, and a NaN operand (0 * inf) must be ignored exactly like
 // OpenCL fmin/fmax do -- which is what v_min_f32 / v_max_f32 implement in IEEE mode.
-// 1/x, correctly rounded (= prt_recip, the IEEE divide the CPU side does), in 6 vector instructions instead of the
-// 11 of the compiler's divide expansion: hardware estimate + one fma Newton step is exact whenever neither x nor
-// 1/x is subnormal (checked over all 2^32 inputs by prt_selftest_math fn 17, tests/test_gpu_parity.py); the rest
-// (zero, subnormal, huge, inf, nan) takes the divide.
-#ifndef PT_RECIP_STEPS
-#define PT_RECIP_STEPS 1
-#endif
-PT_DEV float hw_recip(float x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const unsigned e = (prt_f2u(x) >> 23) & 0xffu;
-    if (e - 2u < 251u) {                                        // 2^-125 <= |x| < 2^126
-        float r = __builtin_amdgcn_rcpf(x);
-        for (int k = 0; k < PT_RECIP_STEPS; ++k) r = __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
-        return r;
-    }
-#endif
-    return 1.0f / x;
-}
 PT_DEV float hw_min(float a, float b) { return __builtin_fminf(a, b); }
 PT_DEV float hw_max(float a, float b) { return __builtin_fmaxf(a, b); }
 
@@ -91,7 +106,7 @@ struct Frame { f3 normal, tangent, bitangent; };
 PT_DEV Frame make_frame(f3 n) {                                 // kernels/header.cl:179-192
     Frame f;
     float sn = prt_copysign(1.0f, n.z);
-    float a = -1.0f / (sn + n.z);
+    float a = -hw_recip(sn + n.z);                       // -1.0f / (sn + n.z): rounding is symmetric
     float b = n.x * n.y * a;
     f.normal = n;
     f.tangent = F3(1.0f + sn * n.x * n.x * a, sn * b, -sn * n.x);
@@ -133,13 +148,13 @@ PT_DEV Mat load_mat(const DevMaterial* m) {
 PT_DEV f3 uniform_sphere(float xi_x, float xi_y) {
     float phi = xi_x * PT_TWO_PI;
     float z = xi_y * 2.0f - 1.0f;
-    float r = prt_sqrt(prt_fmax(1.0f - z * z, 0.0f));
+    float r = hw_sqrt(prt_fmax(1.0f - z * z, 0.0f));
     return F3(prt_cos(phi) * r, prt_sin(phi) * r, z);
 }
 PT_DEV f3 cosine_hemisphere(float xi_x, float xi_y) {
     float phi = xi_x * PT_TWO_PI;
-    float r = prt_sqrt(xi_y);
-    return F3(prt_cos(phi) * r, prt_sin(phi) * r, prt_sqrt(prt_fmax(1.0f - xi_y, 0.0f)));
+    float r = hw_sqrt(xi_y);
+    return F3(prt_cos(phi) * r, prt_sin(phi) * r, hw_sqrt(prt_fmax(1.0f - xi_y, 0.0f)));
 }
 PT_DEV bool check_reflection(f3 wi, f3 wo) {                     // utils.cl:50-52
     return prt_fabs(wi.z * wo.z - wi.x * wo.x - wi.y * wo.y - 1.0f) < 1e-3f;
@@ -186,7 +201,7 @@ PT_DEV Ray create_cam_ray(int cx, int cy, int width, int height, const DevCamera
         float random1 = next1D(rng);
         float random2 = next1D(rng);
         float angle = 2 * PT_PI * random1;
-        float distance = cam.apertureRadius * prt_sqrt(random2);
+        float distance = cam.apertureRadius * hw_sqrt(random2);
         float apertureX = prt_cos(angle) * distance;
         float apertureY = prt_sin(angle) * distance;
         aperturePoint = position + (hAxis * apertureX) + (vAxis * apertureY);
@@ -428,7 +443,7 @@ PT_DEV bool hit_sphere(const DevSphere& s, const Ray& ray, float& best_t) {
     float C = dot(p, p) - s.radius * s.radius;
     float detSq = B * B - C;
     if (detSq >= 0.0f) {
-        float det = prt_sqrt(detSq);
+        float det = hw_sqrt(detSq);
         float t = -B - det;
         if (t < best_t && t > PT_EPS) { best_t = t; return true; }
         t = -B + det;
@@ -468,7 +483,6 @@ PT_DEV bool hit_quad(const DevQuad& qd, const Ray& ray, float& best_t, f3& q_out
     q_out = q;
     return true;
 }
-
 // ---- raymarched SDF primitives, kernels/geometry/sdf.cl:5-118 ("next" row N4) ---------------------------
 PT_DEV f3 vabs3(f3 a) { return F3(prt_fabs(a.x), prt_fabs(a.y), prt_fabs(a.z)); }
 PT_DEV f3 vmax0(f3 a) { return F3(prt_fmax(a.x, 0.0f), prt_fmax(a.y, 0.0f), prt_fmax(a.z, 0.0f)); }
@@ -594,7 +608,7 @@ struct LightSample { f3 d; float dist, pdf; };
 
 PT_DEV float sphere_direct_pdf(const DevSphere& s, f3 p) {
     float dist = length(ld3(s.pos) - p);
-    float cosTheta = prt_sqrt(prt_fmax(dist * dist - s.radius * s.radius, 0.0f)) / dist;
+    float cosTheta = hw_sqrt(prt_fmax(dist * dist - s.radius * s.radius, 0.0f)) / dist;
     return PT_INV_TWO_PI / (1.0f - cosTheta);
 }
 PT_DEV bool sphere_sample_direct(const DevSphere& s, f3 p, LightSample& ls, Rng& rng) {
@@ -603,12 +617,12 @@ PT_DEV bool sphere_sample_direct(const DevSphere& s, f3 p, LightSample& ls, Rng&
     float C = d * d - s.radius * s.radius;
     if (C <= 0.0f) return false;
     L = normalize(L);
-    float cosTheta = prt_sqrt(C) / d;
+    float cosTheta = hw_sqrt(C) / d;
     float xi_x = next1D(rng), xi_y = next1D(rng);
     (void)xi_x;                                  // the cap's azimuth is sampled and then discarded (sphere.cl:76-84)
     float z = xi_y * (1.0f - cosTheta) + cosTheta;
     float B = d * z;
-    float det = prt_sqrt(prt_fmax(B * B - C, 0.0f));
+    float det = hw_sqrt(prt_fmax(B * B - C, 0.0f));
     ls.dist = B - det;
     Frame frame = make_frame(L);
     ls.d = to_global(frame, splat(cosTheta));
@@ -622,7 +636,7 @@ PT_DEV bool quad_sample_direct(const DevQuad& qd, f3 p, LightSample& ls, Rng& rn
     f3 q = base + ld3(qd.edge0) * xi_x + ld3(qd.edge1) * xi_y;
     ls.d = q - p;
     float rSq = dot(ls.d, ls.d);
-    ls.dist = prt_sqrt(rSq);
+    ls.dist = hw_sqrt(rSq);
     ls.d = ls.d / ls.dist;
     float cosTheta = -dot(normal, ls.d);
     ls.pdf = rSq / (cosTheta * qd.area);
@@ -652,8 +666,8 @@ PT_DEV float conductor_reflectance(float eta, float k, float cosThetaI) {
     float sinThetaISq = prt_fmax(1.0f - cosThetaISq, 0.0f);
     float sinThetaIQu = sinThetaISq * sinThetaISq;
     float innerTerm = eta * eta - k * k - sinThetaISq;
-    float aSqPlusBSq = prt_sqrt(prt_fmax(innerTerm * innerTerm + 4.0f * eta * eta * k * k, 0.0f));
-    float a = prt_sqrt(prt_fmax((aSqPlusBSq + innerTerm) * 0.5f, 0.0f));
+    float aSqPlusBSq = hw_sqrt(prt_fmax(innerTerm * innerTerm + 4.0f * eta * eta * k * k, 0.0f));
+    float a = hw_sqrt(prt_fmax((aSqPlusBSq + innerTerm) * 0.5f, 0.0f));
     float Rs = ((aSqPlusBSq + cosThetaISq) - (2.0f * a * cosThetaI)) / ((aSqPlusBSq + cosThetaISq) + (2.0f * a * cosThetaI));
     float Rp = ((cosThetaISq * aSqPlusBSq + sinThetaIQu) - (2.0f * a * cosThetaI * sinThetaISq)) /
                ((cosThetaISq * aSqPlusBSq + sinThetaIQu) + (2.0f * a * cosThetaI * sinThetaISq));
@@ -663,10 +677,10 @@ PT_DEV f3 conductor_reflectance3(f3 eta, f3 k, float c) {
     return F3(conductor_reflectance(eta.x, k.x, c), conductor_reflectance(eta.y, k.y, c), conductor_reflectance(eta.z, k.z, c));
 }
 PT_DEV float dielectric_reflectance(float eta, float cosThetaI, float& cosThetaT) {
-    if (cosThetaI < 0.0f) { eta = 1.0f / eta; cosThetaI = -cosThetaI; }
+    if (cosThetaI < 0.0f) { eta = hw_recip(eta); cosThetaI = -cosThetaI; }
     float sinThetaTSq = eta * eta * (1.0f - cosThetaI * cosThetaI);
     if (sinThetaTSq > 1.0f) { cosThetaT = 0.0f; return 1.0f; }
-    cosThetaT = prt_sqrt(prt_fmax(1.0f - sinThetaTSq, 0.0f));
+    cosThetaT = hw_sqrt(prt_fmax(1.0f - sinThetaTSq, 0.0f));
     float Rs = (eta * cosThetaI - cosThetaT) / (eta * cosThetaI + cosThetaT);
     float Rp = (eta * cosThetaT - cosThetaI) / (eta * cosThetaT + cosThetaI);
     return (Rs * Rs + Rp * Rp) * 0.5f;
@@ -700,20 +714,20 @@ PT_DEV float mf_G1(unsigned dist, float alpha, f3 v, f3 m) {
     if (dot(v, m) * v.z <= 0.0f) return 0.0f;
     if (dist & PRT_DIST_BECKMANN) {
         float cosThetaSq = v.z * v.z;
-        float tanTheta = prt_fabs(prt_sqrt(prt_fmax(1.0f - cosThetaSq, 0.0f)) / v.z);
-        float a = 1.0f / (alpha * tanTheta);
+        float tanTheta = prt_fabs(hw_sqrt(prt_fmax(1.0f - cosThetaSq, 0.0f)) / v.z);
+        float a = hw_recip(alpha * tanTheta);
         if (a < 1.6f) return (3.535f * a + 2.181f * a * a) / (1.0f + 2.276f * a + 2.577f * a * a);
         return 1.0f;
     } else if (dist & PRT_DIST_PHONG) {
         float cosThetaSq = v.z * v.z;
-        float tanTheta = prt_fabs(prt_sqrt(prt_fmax(1.0f - cosThetaSq, 0.0f)) / v.z);
-        float a = prt_sqrt(0.5f * alpha + 1.0f) / tanTheta;
+        float tanTheta = prt_fabs(hw_sqrt(prt_fmax(1.0f - cosThetaSq, 0.0f)) / v.z);
+        float a = hw_sqrt(0.5f * alpha + 1.0f) / tanTheta;
         if (a < 1.6f) return (3.535f * a + 2.181f * a * a) / (1.0f + 2.276f * a + 2.577f * a * a);
         return 1.0f;
     } else if (dist & PRT_DIST_GGX) {
         float alphaSq = alpha * alpha, cosThetaSq = v.z * v.z;
         float tanThetaSq = prt_fmax(1.0f - cosThetaSq, 0.0f) / cosThetaSq;
-        return 2.0f / (1.0f + prt_sqrt(1.0f + alphaSq * tanThetaSq));
+        return 2.0f / (1.0f + hw_sqrt(1.0f + alphaSq * tanThetaSq));
     }
     return 0.0f;
 }
@@ -724,14 +738,14 @@ PT_DEV f3 mf_sample(unsigned dist, float alpha, float xi_x, float xi_y) {
     float cosTheta = 0.0f;
     if (dist & PRT_DIST_BECKMANN) {
         float tanThetaSq = -alpha * alpha * prt_log(1.0f - xi_x);
-        cosTheta = 1.0f / prt_sqrt(1.0f + tanThetaSq);
+        cosTheta = hw_recip(hw_sqrt(1.0f + tanThetaSq));
     } else if (dist & PRT_DIST_PHONG) {
-        cosTheta = prt_pow(xi_x, 1.0f / (alpha + 2.0f));
+        cosTheta = prt_pow(xi_x, hw_recip(alpha + 2.0f));
     } else if (dist & PRT_DIST_GGX) {
         float tanThetaSq = alpha * alpha * xi_x / (1.0f - xi_x);
-        cosTheta = 1.0f / prt_sqrt(1.0f + tanThetaSq);
+        cosTheta = hw_recip(hw_sqrt(1.0f + tanThetaSq));
     }
-    float r = prt_sqrt(prt_fmax(1.0f - cosTheta * cosTheta, 0.0f));
+    float r = hw_sqrt(prt_fmax(1.0f - cosTheta * cosTheta, 0.0f));
     return F3(prt_cos(phi) * r, prt_sin(phi) * r, cosTheta);
 }
 
@@ -819,7 +833,7 @@ PT_DEV f3 absorb_weight(f3 weight, const Mat& mat, bool backside, float ray_t) {
 }
 // Dielectric.cl:4-87
 PT_DEV bool dielectric_sample(Event& e, const Mat& mat, bool backside, float ray_t, Rng& rng) {
-    const float eta = e.wi.z < 0.0f ? mat.eta.x : 1.0f / mat.eta.x;
+    const float eta = e.wi.z < 0.0f ? mat.eta.x : hw_recip(mat.eta.x);
     float cosThetaT = 0.0f;
     float F = dielectric_reflectance(eta, prt_fabs(e.wi.z), cosThetaT);
     if (next1D(rng) < F) {
@@ -838,7 +852,7 @@ PT_DEV bool dielectric_sample(Event& e, const Mat& mat, bool backside, float ray
     return true;
 }
 PT_DEV f3 dielectric_eval(const Event& e, const Mat& mat) {
-    const float eta = e.wi.z < 0.0f ? mat.eta.x : 1.0f / mat.eta.x;
+    const float eta = e.wi.z < 0.0f ? mat.eta.x : hw_recip(mat.eta.x);
     float cosThetaT = 0.0f;
     float F = dielectric_reflectance(eta, prt_fabs(e.wi.z), cosThetaT);
     if (e.wi.z * e.wo.z >= 0.0f) {
@@ -849,7 +863,7 @@ PT_DEV f3 dielectric_eval(const Event& e, const Mat& mat) {
     return splat(0.0f);
 }
 PT_DEV float dielectric_pdf(const Event& e, const Mat& mat) {
-    const float eta = e.wi.z < 0.0f ? mat.eta.x : 1.0f / mat.eta.x;
+    const float eta = e.wi.z < 0.0f ? mat.eta.x : hw_recip(mat.eta.x);
     float cosThetaT = 0.0f;
     float F = dielectric_reflectance(eta, prt_fabs(e.wi.z), cosThetaT);
     if (e.wi.z * e.wo.z >= 0.0f) return check_reflection(e.wi, e.wo) ? F : 0.0f;
@@ -857,14 +871,14 @@ PT_DEV float dielectric_pdf(const Event& e, const Mat& mat) {
 }
 PT_DEV float dielectric_eta(const Event& e, const Mat& mat) {   // Dielectric.cl:82-87 == RoughDielectric.cl:132-137
     if (e.wi.z * e.wo.z >= 0.0f) return 1.0f;
-    return e.wi.z < 0.0f ? mat.eta.x : 1.0f / mat.eta.x;
+    return e.wi.z < 0.0f ? mat.eta.x : hw_recip(mat.eta.x);
 }
 // RoughDielectric.cl:4-137
 PT_DEV float sgnE(float t) { return t < 0.0f ? -1.0f : 1.0f; }
 PT_DEV bool rough_dielectric_sample(Event& e, const Mat& mat, bool backside, float ray_t, Rng& rng) {
     const float wiDotN = e.wi.z;
-    const float eta = e.wi.z < 0.0f ? mat.eta.x : 1.0f / mat.eta.x;
-    float sampleRoughness = (1.2f - 0.2f * prt_sqrt(prt_fabs(wiDotN))) * mat.roughness;
+    const float eta = e.wi.z < 0.0f ? mat.eta.x : hw_recip(mat.eta.x);
+    float sampleRoughness = (1.2f - 0.2f * hw_sqrt(prt_fabs(wiDotN))) * mat.roughness;
     float alpha = roughness_to_alpha(mat.dist, mat.roughness);
     float sampleAlpha = roughness_to_alpha(mat.dist, sampleRoughness);
     float xi_x = next1D(rng), xi_y = next1D(rng);
@@ -873,8 +887,8 @@ PT_DEV bool rough_dielectric_sample(Event& e, const Mat& mat, bool backside, flo
     if (pm < 1e-10f) return false;
     float wiDotM = dot(e.wi, m);
     float cosThetaT = 0.0f;
-    float F = dielectric_reflectance(1.0f / mat.eta.x, wiDotM, cosThetaT);
-    float etaM = wiDotM < 0.0f ? mat.eta.x : 1.0f / mat.eta.x;
+    float F = dielectric_reflectance(hw_recip(mat.eta.x), wiDotM, cosThetaT);
+    float etaM = wiDotM < 0.0f ? mat.eta.x : hw_recip(mat.eta.x);
     bool reflect = next1D(rng) < F;
     if (reflect) e.wo = m * (2.0f * wiDotM) - e.wi;
     else e.wo = m * (etaM * wiDotM - sgnE(wiDotM) * cosThetaT) - e.wi * etaM;
@@ -904,11 +918,11 @@ PT_DEV f3 rough_dielectric_eval(const Event& e, const Mat& mat) {
     float wiDotN = e.wi.z, woDotN = e.wo.z;
     bool reflect = wiDotN * woDotN >= 0.0f;
     float alpha = roughness_to_alpha(mat.dist, mat.roughness);
-    const float eta = wiDotN < 0.0f ? mat.eta.x : 1.0f / mat.eta.x;
+    const float eta = wiDotN < 0.0f ? mat.eta.x : hw_recip(mat.eta.x);
     f3 m = rough_diel_half(e, eta, reflect);
     float wiDotM = dot(e.wi, m), woDotM = dot(e.wo, m);
     float cosThetaT = 0.0f;
-    float F = dielectric_reflectance(1.0f / mat.eta.x, wiDotM, cosThetaT);
+    float F = dielectric_reflectance(hw_recip(mat.eta.x), wiDotM, cosThetaT);
     float G = mf_G(mat.dist, alpha, e.wi, e.wo, m);
     float D = mf_D(mat.dist, alpha, m);
     float fx;
@@ -923,13 +937,13 @@ PT_DEV f3 rough_dielectric_eval(const Event& e, const Mat& mat) {
 PT_DEV float rough_dielectric_pdf(const Event& e, const Mat& mat) {
     float wiDotN = e.wi.z, woDotN = e.wo.z;
     bool reflect = wiDotN * woDotN >= 0.0f;
-    float sampleRoughness = (1.2f - 0.2f * prt_sqrt(prt_fabs(wiDotN))) * mat.roughness;
+    float sampleRoughness = (1.2f - 0.2f * hw_sqrt(prt_fabs(wiDotN))) * mat.roughness;
     float sampleAlpha = roughness_to_alpha(mat.dist, sampleRoughness);
-    float eta = wiDotN < 0.0f ? mat.eta.x : 1.0f / mat.eta.x;
+    float eta = wiDotN < 0.0f ? mat.eta.x : hw_recip(mat.eta.x);
     f3 m = rough_diel_half(e, eta, reflect);
     float wiDotM = dot(e.wi, m), woDotM = dot(e.wo, m);
     float cosThetaT = 0.0f;
-    float F = dielectric_reflectance(1.0f / mat.eta.x, wiDotM, cosThetaT);
+    float F = dielectric_reflectance(hw_recip(mat.eta.x), wiDotM, cosThetaT);
     float pm = mf_pdf(mat.dist, sampleAlpha, m);
     if (reflect) return F * pm * 0.25f / prt_fabs(wiDotM);
     float s = eta * wiDotM + woDotM;
@@ -1058,7 +1072,7 @@ PT_DEV float bsdf_pdf(const DevScene& sc, const Event& e, const Mat& mat) {
 // ---- phase functions + medium, kernels/phasefunctions/*.cl, kernels/media/homogeneous.cl:11-51 -------
 PT_DEV float hg(float g, float cosTheta) {
     float term = 1.0f + g * g - 2.0f * g * cosTheta;
-    return PT_INV_FOUR_PI * (1.0f - g * g) / (term * prt_sqrt(term));
+    return PT_INV_FOUR_PI * (1.0f - g * g) / (term * hw_sqrt(term));
 }
 PT_DEV float rayleigh(float cosTheta) { return (3.0f / (16.0f * PT_PI)) * (1.0f + cosTheta * cosTheta); }   // Rayleigh.cl:4-6
 PT_DEV float phase_value(const DevScene& sc, f3 wi, f3 wo) {    // phase_eval (splat) == phase_pdf
@@ -1073,10 +1087,10 @@ PT_DEV void phase_sample(const DevScene& sc, f3 wi, PhaseSample& ps, Rng& rng) {
     if (sc.phase_function == 2) {                                   // Rayleigh.cl:16-39
         float phi = xi_x * PT_TWO_PI;
         float z = xi_y * 4.0f - 2.0f;
-        float invZ = prt_sqrt(z * z + 1.0f);
+        float invZ = hw_sqrt(z * z + 1.0f);
         float u = prt_cbrt(z + invZ);
-        float cosTheta = u - 1.0f / u;
-        float sinTheta = prt_sqrt(prt_fmax(1.0f - cosTheta * cosTheta, 0.0f));
+        float cosTheta = u - hw_recip(u);
+        float sinTheta = hw_sqrt(prt_fmax(1.0f - cosTheta * cosTheta, 0.0f));
         Frame tf = make_frame(wi);
         ps.w = to_global(tf, F3(prt_cos(phi) * sinTheta, prt_sin(phi) * sinTheta, cosTheta));
         ps.pdf = rayleigh(cosTheta);
@@ -1085,7 +1099,7 @@ PT_DEV void phase_sample(const DevScene& sc, f3 wi, PhaseSample& ps, Rng& rng) {
         float phi = xi_x * PT_TWO_PI;
         float q = (1.0f - g * g) / (1.0f + g * (xi_y * 2.0f - 1.0f));
         float cosTheta = (1.0f + g * g - q * q) / (2.0f * g);
-        float sinTheta = prt_sqrt(prt_fmax(1.0f - cosTheta * cosTheta, 0.0f));
+        float sinTheta = hw_sqrt(prt_fmax(1.0f - cosTheta * cosTheta, 0.0f));
         Frame tf = make_frame(wi);
         ps.w = to_global(tf, F3(prt_cos(phi) * sinTheta, prt_sin(phi) * sinTheta, cosTheta));
         ps.pdf = hg(g, cosTheta);

@@ -130,6 +130,16 @@ __global__ void selftest_math_kernel(int fn, const float* __restrict__ a, const 
         out[i] = (float)bad;
         return;
     }
+    if (fn == 19) {         // exhaustive: hw_sqrt against the IEEE square root on the 65536 bit patterns (i << 16) + k
+        unsigned bad = 0;
+        for (unsigned k = 0; k < 65536u; ++k) {
+            const float v = prt_u2f(((unsigned)i << 16) + k);
+            const float q = __builtin_sqrtf(v), h = hw_sqrt(v);
+            if (prt_f2u(q) != prt_f2u(h) && !(q != q && h != h)) ++bad;
+        }
+        out[i] = (float)bad;
+        return;
+    }
     if (fn == 18) {         // exhaustive: out_of_unit_range(x, c, u) against the divide, c = b[0], x = the 65536 patterns (i << 16) + k
         const float c = b[0];
         const float u = (c >= 9.094947017729282e-13f && c <= 1099511627776.0f) ? c * 5.9604644775390625e-08f : prt_u2f(0x7fc00000u);

@@ -505,6 +505,17 @@ def test_fast_reciprocal_is_the_ieee_divide_on_every_float(prt):
     assert bad.sum() == 0, "hw_recip differs from 1.0f/x on %d inputs" % int(bad.sum())
 
 
+def test_fast_square_root_is_the_ieee_one_on_every_float(prt):
+    """hw_sqrt (hardware 1/sqrt estimate, x * r, one fma correction step; the IEEE expansion outside 2^-100 .. 2^100) replaces the
+    square roots of the device code; it must be the correctly rounded square root for all 2^32 inputs"""
+    scene = prt.HostScene("cornell_diffuse.json")
+    r = prt.Renderer(scene.config(), device=0)
+    z = np.zeros(65536, dtype=np.float32)
+    bad = r.selftest_math(19, z, z)
+    r.close()
+    assert bad.sum() == 0, "hw_sqrt differs from sqrtf(x) on %d inputs" % int(bad.sum())
+
+
 @pytest.mark.parametrize("c", [1.0, 3.0, 0.7531, 16777215.0, 1.1920929e-07 * 3, 2.0 ** 40, 2.0 ** -40, 2.0 ** 41, 1e-20, 0.0, 5.960465e-08])
 def test_quad_edge_predicate_is_the_divide_on_every_float(prt, c):
     """hit_quad compares x / c with 0 and 1 without dividing (pt_device.h out_of_unit_range); the predicate must equal
