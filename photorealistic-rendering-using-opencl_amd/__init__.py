@@ -22,7 +22,7 @@ REPO = os.path.dirname(HERE)
 SCENES_DIR = os.path.join(REPO, "scenes")
 MODELS_DIR = os.path.join(SCENES_DIR, "models")
 
-__all__ = ["ensure_dragon_standin", "HostScene", "Renderer", "default_camera", "orbit_camera", "seed_pairs", "make_sky", "load_hdr", "PrtError",
+__all__ = ["ensure_dragon_standin", "HostScene", "Renderer", "default_camera", "orbit_camera", "seed_pairs", "make_sky", "load_hdr", "write_hdr", "PrtError",
            "Camera", "Config", "SceneDesc", "Stats", "PATH_STATE_DTYPE", "SCENES_DIR", "MODELS_DIR", "build"]
 
 
@@ -141,6 +141,16 @@ def load_hdr(path):
         return np.ctypeslib.as_array(data, shape=(h.value, w.value, 3)).copy()
     finally:
         lib.prth_hdr_free(handle)
+
+
+def write_hdr(path, pixels, bottom_up=True):
+    """saveImage() with `-encoder 1` of the reference (include/GL/cl_gl_interop.h:151-156): float32 [h, w, 3 or 4] -> a Radiance .hdr file"""
+    pixels = np.ascontiguousarray(pixels, dtype=np.float32)
+    assert pixels.ndim == 3 and pixels.shape[2] >= 3
+    err = C.create_string_buffer(256)
+    if load_library().prth_hdr_write(os.fsencode(path), pixels.ctypes.data_as(C.c_void_p), pixels.shape[1], pixels.shape[0], pixels.shape[2],
+                                     1 if bottom_up else 0, err, 256):
+        raise PrtError("write_hdr: %s" % err.value.decode())
 
 
 class Renderer:

@@ -117,6 +117,7 @@ PRTH_API = [
     ("prth_make_sky", C.c_int, [C.c_int, C.c_int, C.c_void_p]),
     ("prth_hdr_load", C.c_void_p, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_float)), C.c_char_p, C.c_int]),
     ("prth_hdr_free", None, [C.c_void_p]),
+    ("prth_hdr_write", C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]),
 ]
 
 _lib = None

@@ -34,6 +34,8 @@ struct prt_ctx {
     void* d_pairs = nullptr; void* d_tri_geom = nullptr; void* d_tri_nrm = nullptr;
     void* d_spheres = nullptr; void* d_quads = nullptr; void* d_sdfs = nullptr; void* d_mats = nullptr; void* d_env = nullptr;
     bool have_scene = false, have_cam = false, have_size = false;
+    bool state_undefined = false;   // a render call failed half-way (prt_render_spp's abort path): pixels may be ahead of the launch windows
+                                    // (run-ahead leads in the state) -- the state is unusable until prt_reset / prt_write_state
     DevCamera cam{};
     // frame
     int width = 0, full_height = 0, row0 = 0, rows = 0;
@@ -298,6 +300,7 @@ extern "C" int prt_reset(prt_ctx* c) {
     CTX_CHECK(c);
     if (!c->have_size) return fail(c, PRT_ERR_NOT_READY, "prt_reset: no frame size set");
     HIPCHK(c, hipSetDevice(c->device));
+    c->state_undefined = false;
     // enqueueFillBuffer(cl_flattenI, 0, ...), src/main.cpp:288
     HIPCHK(c, hipMemsetAsync(c->S.q0, 0, c->npix * 16, c->stream));
     HIPCHK(c, hipMemsetAsync(c->S.q1, 0, c->npix * 16, c->stream));
@@ -320,6 +323,7 @@ static int ensure_seeds(prt_ctx* c, const int32_t* seed_pairs, size_t n_frames) 
 }
 
 static int ready(prt_ctx* c, const char* who) {
+    if (c->state_undefined) return fail(c, PRT_ERR_NOT_READY, std::string(who) + ": an earlier render call failed half-way; prt_reset or prt_write_state first");
     if (!c->have_scene) return fail(c, PRT_ERR_NOT_READY, std::string(who) + ": no scene uploaded");
     if (!c->have_cam) return fail(c, PRT_ERR_NOT_READY, std::string(who) + ": no camera set");
     if (!c->have_size) return fail(c, PRT_ERR_NOT_READY, std::string(who) + ": no frame size set");
@@ -434,6 +438,7 @@ extern "C" int prt_render_spp(prt_ctx* c, uint32_t spp, uint32_t max_frames, con
             (void)hipMemsetAsync(c->d_counters + 4, 0, 2 * prt_ctx::MAX_SUB * sizeof(unsigned long long), c->stream);
             (void)hipStreamSynchronize(c->stream);
             (void)hipGetLastError();
+            c->state_undefined = true;
             return fail(c, code, msg);
         };
 #define SUBCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return abort_streams(PRT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
@@ -610,6 +615,7 @@ extern "C" int prt_write_state(prt_ctx* c, const prt_path_state* state) {
     if (e == hipSuccess) { launch_rtd_to_state(d, c->S, c->fb, c->npix, c->stream); e = hipStreamSynchronize(c->stream); }
     (void)hipFree(d);
     HIPCHK(c, e);
+    c->state_undefined = false;
     return PRT_OK;
 }
 

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene 
         L.diff = e.y & 0xffffu; L.spec = e.y >> 16;
         L.trans = e.z & 0xffffu; L.scatters = e.z >> 16;
         L.wasSpecular = (e.w & 1u) != 0; L.reset = (e.w & 2u) != 0;
-        L.f = e.w >> 2;                                         // frames of this launch done in an earlier one (run_ahead)
+        L.f = fa.run_ahead ? e.w >> 2 : 0u;                     // frames of this launch done in an earlier one ("N spp" launches only)
     }
     extern __shared__ unsigned lds_stack[];                     // sc.stack_levels x PT_BLOCK, sized by the launch
     TravStack stk;

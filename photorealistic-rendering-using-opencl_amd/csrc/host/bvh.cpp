@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <mutex>
 #include <numeric>
+#include <system_error>
 #include <thread>
 
 namespace prt {
@@ -68,7 +69,10 @@ void BVH::build(const std::vector<float>& tb, const std::vector<float>& ce) {
     auto lap = [&](const char* what) {
         if (std::getenv("PRT_BVH_TIMING")) std::fprintf(stderr, "BVH %s: %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
     };
+    // the machine's threads, shared with the other ranks of a multi-process launch (torchrun exports LOCAL_WORLD_SIZE: eight ranks that
+    // each build the same 871 k-triangle tree must not start 8 x 64 threads); PRT_BVH_THREADS overrides
     unsigned n_threads = std::thread::hardware_concurrency();
+    if (const char* e = std::getenv("LOCAL_WORLD_SIZE")) { const int k = std::atoi(e); if (k > 1) n_threads = (n_threads + (unsigned)k - 1u) / (unsigned)k; }
     if (const char* e = std::getenv("PRT_BVH_THREADS")) n_threads = (unsigned)std::atoi(e);
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 64) n_threads = 64;
@@ -81,10 +85,17 @@ void BVH::build(const std::vector<float>& tb, const std::vector<float>& ce) {
             std::iota(order[a].begin(), order[a].end(), 0u);
             std::stable_sort(order[a].begin(), order[a].end(), [&](uint32_t x, uint32_t y) { return ce[3 * x + a] < ce[3 * y + a]; });
         };
+        // (a thread that cannot be started -- a process / thread limit on the box -- is work done here instead: the tree does not
+        // depend on who builds what)
+        auto spawn = [](std::thread& th, auto&& fn, int a) { try { th = std::thread(fn, a); return true; } catch (const std::system_error&) { return false; } };
         if (n_threads > 1) {
-            std::thread t1(sort_axis, 1), t2(sort_axis, 2);
+            std::thread t1, t2;
+            const bool s1 = spawn(t1, sort_axis, 1), s2 = spawn(t2, sort_axis, 2);
             sort_axis(0);
-            t1.join(); t2.join();
+            if (!s1) sort_axis(1);
+            if (!s2) sort_axis(2);
+            if (s1) t1.join();
+            if (s2) t2.join();
         } else {
             for (int a = 0; a < 3; ++a) sort_axis(a);
         }
@@ -153,9 +164,14 @@ void BVH::build(const std::vector<float>& tb, const std::vector<float>& ce) {
                 }
             };
             if (n_threads > 1 && count > 65536u) {
-                std::thread t1(sweep, 1), t2(sweep, 2);
+                auto spawn = [](std::thread& th, auto&& fn, int a) { try { th = std::thread(fn, a); return true; } catch (const std::system_error&) { return false; } };
+                std::thread t1, t2;
+                const bool s1 = spawn(t1, sweep, 1), s2 = spawn(t2, sweep, 2);
                 sweep(0);
-                t1.join(); t2.join();
+                if (!s1) sweep(1);
+                if (!s2) sweep(2);
+                if (s1) t1.join();
+                if (s2) t2.join();
             } else {
                 for (int a = 0; a < 3; ++a) sweep(a);
             }
@@ -225,7 +241,9 @@ void BVH::build(const std::vector<float>& tb, const std::vector<float>& ce) {
     };
     if (n_threads > 1) {
         std::vector<std::thread> pool;
-        for (unsigned k = 1; k < n_threads; ++k) pool.emplace_back(worker);
+        for (unsigned k = 1; k < n_threads; ++k) {
+            try { pool.emplace_back(worker); } catch (const std::system_error&) { break; }      // fewer workers, the same tree
+        }
         worker();
         for (auto& th : pool) th.join();
     } else {

@@ -63,7 +63,16 @@ bool decode_hdr(const unsigned char* data, size_t size, std::vector<float>& rgb,
         err = "unreasonable picture size";
         return false;
     }
-    if ((size - r.pos) < (size_t)h * 4) { err = "truncated pixel data"; return false; }      // cheapest possible encoding still needs this
+    // The decoded picture is allocated only if the bytes that are left can encode it: flat data needs 4 bytes per pixel, a
+    // run-length scanline its 4-byte header and, per channel, 2 bytes for every run of at most 127 pixels -- so the memory a
+    // file can claim is bounded by a fixed multiple (~190 x) of its own size.
+    {
+        const bool rle_possible = !(w < 8 || w >= 32768);
+        const unsigned long long flat_bytes = 4ull * (unsigned long long)w * (unsigned long long)h;
+        const unsigned long long rle_bytes = (unsigned long long)h * (4ull + 8ull * (unsigned long long)((w + 126) / 127));
+        const unsigned long long need = (rle_possible && rle_bytes < flat_bytes) ? rle_bytes : flat_bytes;
+        if ((unsigned long long)(size - r.pos) < need) { err = "truncated pixel data"; return false; }
+    }
     width = (int)w; height = (int)h;
     rgb.assign((size_t)w * h * 3, 0.0f);
     std::vector<unsigned char> scan((size_t)w * 4);
@@ -86,9 +95,12 @@ bool decode_hdr(const unsigned char* data, size_t size, std::vector<float>& rgb,
         unsigned char hd[4];
         for (int k = 0; k < 4; ++k) { const int c = r.get(); if (c < 0) { err = "truncated pixel data"; return false; } hd[k] = (unsigned char)c; }
         if (hd[0] != 2 || hd[1] != 2 || (hd[2] & 0x80)) {
-            // not run-length encoded: the four bytes are the first pixel of flat data (only legal on the first scanline;
-            // later on it would be a corrupt file, which decodes the same way the reference's loader does)
-            return flat_from((size_t)j * w, hd, 4);
+            // not run-length encoded: the four bytes are the first pixel of flat data.  Only the first scanline can say so; a
+            // later one without the run-length header is a corrupt file (the reference's stb loader would restart the whole
+            // picture as flat data from there; refused here)
+            if (j != 0) { err = "corrupt run-length data (scanline without a run-length header)"; return false; }
+            if ((unsigned long long)(size - r.pos) + 4ull < 4ull * (unsigned long long)w * (unsigned long long)h) { err = "truncated pixel data"; return false; }
+            return flat_from(0, hd, 4);
         }
         if ((((long)hd[2]) << 8 | hd[3]) != w) { err = "corrupt run-length scanline (width mismatch)"; return false; }
         for (int ch = 0; ch < 4; ++ch) {
@@ -129,6 +141,56 @@ bool load_hdr(const std::string& path, std::vector<float>& rgb, int& width, int&
     }
     std::fclose(f);
     if (!decode_hdr(buf.data(), buf.size(), rgb, width, height, err)) { err = path + ": " + err; return false; }
+    return true;
+}
+
+// ---- writer: `-encoder 1` of the reference (saveImage, include/GL/cl_gl_interop.h:151-156 -> stbi_write_hdr) -------------------
+// Radiance RGBE as the format defines it: the largest component m of a pixel fixes the shared exponent e with 2^(e-1) <= m < 2^e,
+// each component is stored as floor(c * 256 / 2^e) and the exponent byte as e + 128; a pixel whose largest component is below
+// 1e-32 is four zero bytes.  Scanlines are run-length encoded per channel (widths 8 .. 32767), rows top to bottom.
+namespace {
+void float_to_rgbe(const float* c, unsigned char* q) {
+    const float m = std::fmax(c[0], std::fmax(c[1], c[2]));
+    if (!(m >= 1e-32f)) { q[0] = q[1] = q[2] = q[3] = 0; return; }                 // (a NaN or negative picture value ends here too)
+    int e = 0;
+    const float scale = std::frexp(m, &e) * 256.0f / m;
+    for (int k = 0; k < 3; ++k) { const float v = c[k] * scale; q[k] = (unsigned char)(v > 0.0f ? (v < 255.0f ? (int)v : 255) : 0); }
+    q[3] = (unsigned char)(e + 128);
+}
+void rle_channel(const unsigned char* row, int n, int stride, std::vector<unsigned char>& out) {
+    int i = 0;
+    while (i < n) {
+        int j = i;
+        while (j < n && j - i < 127 && row[(size_t)j * stride] == row[(size_t)i * stride]) ++j;
+        if (j - i >= 3) { out.push_back((unsigned char)(128 + (j - i))); out.push_back(row[(size_t)i * stride]); i = j; continue; }
+        int k = i;                                                  // literals up to the next run of three
+        while (k < n && k - i < 128 &&
+               !(k + 2 < n && row[(size_t)k * stride] == row[(size_t)(k + 1) * stride] && row[(size_t)k * stride] == row[(size_t)(k + 2) * stride])) ++k;
+        out.push_back((unsigned char)(k - i));
+        for (int t = i; t < k; ++t) out.push_back(row[(size_t)t * stride]);
+        i = k;
+    }
+}
+}  // namespace
+
+bool write_hdr(const std::string& path, const float* pixels, int width, int height, int channels, bool bottom_up, std::string& err) {
+    if (!pixels || width <= 0 || height <= 0 || channels < 3) { err = "write_hdr: bad arguments"; return false; }
+    std::vector<unsigned char> out;
+    const std::string head = "#?RADIANCE\n# written by libprt (prt_render -encoder 1)\nFORMAT=32-bit_rle_rgbe\nEXPOSURE=1.0\n\n-Y " +
+                             std::to_string(height) + " +X " + std::to_string(width) + "\n";
+    out.insert(out.end(), head.begin(), head.end());
+    std::vector<unsigned char> scan((size_t)width * 4);
+    for (int j = 0; j < height; ++j) {
+        const float* row = pixels + (size_t)(bottom_up ? height - 1 - j : j) * width * channels;
+        for (int i = 0; i < width; ++i) float_to_rgbe(row + (size_t)i * channels, &scan[(size_t)i * 4]);
+        if (width < 8 || width >= 32768) { out.insert(out.end(), scan.begin(), scan.end()); continue; }
+        out.push_back(2); out.push_back(2); out.push_back((unsigned char)(width >> 8)); out.push_back((unsigned char)(width & 255));
+        for (int ch = 0; ch < 4; ++ch) rle_channel(scan.data() + ch, width, 4, out);
+    }
+    std::FILE* f = std::fopen(path.c_str(), "wb");
+    if (!f) { err = "cannot open " + path + " for writing"; return false; }
+    const bool ok = std::fwrite(out.data(), 1, out.size(), f) == out.size();
+    if (std::fclose(f) != 0 || !ok) { err = "cannot write " + path; return false; }
     return true;
 }
 

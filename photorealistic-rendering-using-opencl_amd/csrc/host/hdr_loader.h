@@ -15,5 +15,10 @@ bool load_hdr(const std::string& path, std::vector<float>& rgb, int& width, int&
 // the same from memory (tests)
 bool decode_hdr(const unsigned char* data, size_t size, std::vector<float>& rgb, int& width, int& height, std::string& err);
 
+// `-encoder 1` of the reference (saveImage -> stbi_write_hdr("render.hdr", w, h, 3, pixels), include/GL/cl_gl_interop.h:151-156):
+// `channels` floats per pixel (the first three are written), rows of `pixels` bottom-up (the framebuffer's order: the reference flips
+// on write, :139) or top-down; the file is top-down, run-length encoded.
+bool write_hdr(const std::string& path, const float* pixels, int width, int height, int channels, bool bottom_up, std::string& err);
+
 }  // namespace IO
 }  // namespace prt

@@ -138,6 +138,15 @@ extern "C" void* prth_hdr_load(const char* path, int* width, int* height, const 
 }
 extern "C" void prth_hdr_free(void* handle) { delete static_cast<std::vector<float>*>(handle); }
 
+extern "C" int prth_hdr_write(const char* path, const float* pixels, int width, int height, int channels, int bottom_up, char* err, int err_len) {
+    std::string e;
+    if (!path || !prt::IO::write_hdr(path, pixels, width, height, channels, bottom_up != 0, e)) {
+        if (err && err_len > 0) { std::strncpy(err, path ? e.c_str() : "null path", (size_t)err_len - 1); err[err_len - 1] = 0; }
+        return 1;
+    }
+    return 0;
+}
+
 extern "C" int prth_make_sky(int w, int h, float* rgb) {
     if (!rgb || w <= 0 || h <= 0) return PRT_ERR_INVALID_ARGUMENT;
     // equirect: u -> azimuth, v -> polar angle from +y (kernels/utils.cl:46).  Gradient sky,

@@ -45,6 +45,9 @@ int prth_make_sky(int width, int height, float* rgb);
  * Returns a handle (prth_hdr_free) or NULL with the reason in err. */
 void* prth_hdr_load(const char* path, int* width, int* height, const float** rgb, char* err, int err_len);
 void prth_hdr_free(void* handle);
+/* the reference's `-encoder 1` (saveImage -> stbi_write_hdr, include/GL/cl_gl_interop.h:151-156): `channels` (>= 3) floats per pixel,
+ * rows bottom-up (bottom_up != 0: the framebuffer's order) or top-down; writes a run-length encoded Radiance picture.  0 on success. */
+int prth_hdr_write(const char* path, const float* pixels, int width, int height, int channels, int bottom_up, char* err, int err_len);
 
 #ifdef __cplusplus
 }

@@ -2,7 +2,7 @@
 // the prt C ABI: same argv flags (-scene -width -height -hdr -alpha), same start-up order
 // (scene -> model -> BVH -> buffers -> camera -> kernel args), same per-frame protocol
 // (frame counter from 1, two rand() values per frame after two consumed at start-up), with the
-// GLFW loop replaced by "-frames N" or "-spp N" and PrtSc replaced by "-out file.pfm".
+// GLFW loop replaced by "-frames N" or "-spp N" and PrtSc replaced by "-out file.{png,hdr,pfm}" (default render.png / render.hdr by -encoder, as saveImage()).
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
@@ -83,7 +83,8 @@ int main(int argc, char** argv) {
     int window_width = 1280, window_height = 720;                 // src/main.cpp:55-57
     std::string scene_filepath = "../scenes/cornell.json";        // :90
     std::string models_directory = "../resources/models/";        // :35
-    std::string env_map_filepath, out_path = "render.pfm";
+    std::string env_map_filepath, out_path;
+    int encoder = 0;                                               // { 0: ".png", 1: ".hdr" }, src/main.cpp:365-367
     bool alpha = false;
     uint32_t view = PRT_VIEW_RESULTS;                              // kernels/main.cl:15: a source edit in the reference, a flag here
     unsigned frames = 0, spp = 16;
@@ -97,7 +98,7 @@ int main(int argc, char** argv) {
         else if (a == "-hdr") env_map_filepath = next();
         else if (a == "-alpha") alpha = true;
         else if (a == "-view") { const std::string v = next(); view = v == "normal" ? PRT_VIEW_NORMAL : v == "bvh_hit" ? PRT_VIEW_BVH_HIT : PRT_VIEW_RESULTS; }
-        else if (a == "-encoder") next();                          // PNG/HDR encoder choice of the GL path: ignored
+        else if (a == "-encoder") encoder = std::atoi(next());
         else if (a == "-models") models_directory = next();
         else if (a == "-frames") frames = (unsigned)std::atoi(next());
         else if (a == "-spp") spp = (unsigned)std::atoi(next());
@@ -168,13 +169,20 @@ int main(int argc, char** argv) {
         CHECK(prt_query_counts(ctx, frames ? 0 : spp, &st));
         std::printf("%dx%d: %llu samples, %llu segments, %.1f ms on the device (%u launches)\n", window_width, window_height,
                     (unsigned long long)st.samples, (unsigned long long)st.segments, st.kernel_ms, st.launches);
-        const bool png = out_path.size() > 4 && out_path.compare(out_path.size() - 4, 4, ".png") == 0;
+        // saveImage(), include/GL/cl_gl_interop.h:144-160: -encoder 0 -> render.png (the displayed, tonemapped picture), -encoder 1 ->
+        // render.hdr (the linear one); -out <file> picks the name, and the format by its extension (.png / .hdr / .pfm)
+        if (out_path.empty()) out_path = encoder == 1 ? "render.hdr" : "render.png";
+        auto ends_with = [&](const char* ext) { return out_path.size() > 4 && out_path.compare(out_path.size() - 4, 4, ext) == 0; };
         bool ok;
-        if (png) {                                                 // encoder 0 of the reference: the tonemapped picture
+        if (ends_with(".png")) {                                   // encoder 0 of the reference: the tonemapped picture
             std::vector<uint8_t> ldr((size_t)window_width * window_height * 4);
             CHECK(prt_tonemap_rgba8(ctx, ldr.data()));
             ok = write_png(out_path, ldr, window_width, window_height);
-        } else {                                                   // encoder 1: the linear picture
+        } else if (ends_with(".hdr")) {                            // encoder 1: the linear picture as Radiance RGBE
+            char herr[256] = "";
+            ok = prth_hdr_write(out_path.c_str(), rgba.data(), window_width, window_height, 4, 1, herr, sizeof(herr)) == 0;
+            if (!ok) std::fprintf(stderr, "%s\n", herr);
+        } else {                                                   // the linear picture, lossless
             ok = write_pfm(out_path, rgba, window_width, window_height);
         }
         if (!ok) { std::fprintf(stderr, "cannot write %s\n", out_path.c_str()); return 1; }

@@ -841,6 +841,17 @@ def test_tonemap_matches_the_reference_shader_and_cli_writes_png(prt, oracle, tm
     assert (pix[:, 0] == 0).all()
     png = pix[:, 1:].reshape(H, W, 4)
     assert np.array_equal(png[::-1], ldr)             # the PNG is top-down, the framebuffer bottom-up; same render (deterministic)
+    # -encoder 1: render.hdr in the working directory, the LINEAR picture as Radiance RGBE (saveImage, include/GL/cl_gl_interop.h:151-156)
+    res = subprocess.run([exe, "-scene", os.path.join(prt.SCENES_DIR, "cornell_coat.json"), "-models", prt.MODELS_DIR + "/",
+                          "-width", str(W), "-height", str(H), "-spp", "4", "-encoder", "1"], cwd=str(tmp_path),
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert res.returncode == 0, res.stdout
+    hdr = prt.load_hdr(str(tmp_path / "render.hdr"))
+    lin = fb[::-1, :, :3]
+    m = lin.max(axis=2)
+    ok = m >= 1e-32
+    assert hdr.shape == lin.shape and (hdr[~ok] == 0).all()
+    assert (np.abs(hdr[ok] - lin[ok]).max(axis=1) <= m[ok] / 127.0).all()      # 8-bit mantissas against the shared exponent
 
 
 def test_device_functions_match_reference_kat(prt):

@@ -109,3 +109,49 @@ def test_cli_refuses_unreadable_hdr(prt, tmp_path):
                         "-hdr", str(tmp_path / "missing.hdr"), "-width", "16", "-height", "16", "-spp", "1", "-out", str(tmp_path / "o.pfm")],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert r.returncode != 0
+
+
+@pytest.mark.parametrize("w,h", [(5, 3), (8, 2), (37, 11), (300, 4)])
+def test_writer_round_trips_through_the_loader(prt, tmp_path, w, h):
+    """`-encoder 1` of the reference (stbi_write_hdr): the file the writer produces, read back, is the picture quantised to RGBE as
+    the format defines it (shared exponent of the largest component, 8-bit mantissas rounded down) -- computed here independently"""
+    rng = np.random.default_rng(w * 100 + h)
+    img = np.exp(rng.uniform(-12, 6, (h, w, 4))).astype(np.float32)
+    img[0, 0, :3] = 0.0                                            # black
+    img[-1, -1, :3] = [1e-35, 0.0, 1e-36]                          # below the format's floor: black
+    if w >= 8:
+        img[h // 2, : w // 2, :3] = [0.25, 0.5, 1.0]               # a run
+    p = str(tmp_path / "out.hdr")
+    prt.write_hdr(p, img, bottom_up=True)
+    back = prt.load_hdr(p)
+    m = img[..., :3].max(axis=2)
+    e = np.frexp(m)[1]
+    mant = np.floor(img[..., :3].astype(np.float64) * np.ldexp(1.0, 8 - e)[..., None]).clip(0, 255)
+    want = (mant * np.ldexp(1.0, e - 8)[..., None]).astype(np.float32)
+    want[m < 1e-32] = 0.0
+    assert back.shape == (h, w, 3)
+    assert np.array_equal(back, want[::-1]), "rows top-down in the file, quantised as RGBE"
+    raw = open(p, "rb").read()
+    assert raw.startswith(b"#?RADIANCE\n") and (b"-Y %d +X %d\n" % (h, w)) in raw
+    if w >= 8:
+        assert len(raw) < 200 + 4 * w * h + 4 * h                  # run-length encoded scanlines
+
+
+def test_loader_refuses_a_header_that_claims_more_than_the_file_can_hold(prt, tmp_path):
+    """the picture is allocated only if the remaining bytes can encode it (flat: 4 B per pixel; run-length: 4 + 8 * ceil(w / 127) per row)"""
+    p = str(tmp_path / "bomb.hdr")
+    _write(p, _header(16384, 16384) + b"\x02\x02\x40\x00" + bytes(60000))
+    with pytest.raises(prt.PrtError, match="truncated"):
+        prt.load_hdr(p)
+    rng = np.random.default_rng(5)
+    w, h = 40, 6                                                   # a run-length header on a later scanline only: corrupt
+    rgbe = rng.integers(1, 255, (h, w, 4), dtype=np.uint8)
+    body = b""
+    for j in range(h):
+        if j == 2:
+            body += rgbe[j].tobytes()
+        else:
+            body += bytes([2, 2, w >> 8, w & 255]) + b"".join(_rle_channel(rgbe[j, :, c].tobytes()) for c in range(4))
+    _write(p, _header(w, h) + body + bytes(4 * w * h))
+    with pytest.raises(prt.PrtError, match="corrupt"):
+        prt.load_hdr(p)

@@ -8,7 +8,7 @@ import struct
 import numpy as np
 import pytest
 
-from conftest import ALPHA_VARIANTS, GOLDEN, VARIANTS
+from conftest import ALPHA_VARIANTS, GOLDEN, ROOT, VARIANTS
 
 
 def read_blob(path):
@@ -111,6 +111,29 @@ def test_bvh_is_a_valid_partition(prt):
                 stack.append(int(c))
     assert seen.all() and visited.all()
     assert scene.bvh_depth < 64                                          # the reference's closest-hit stack size
+
+
+@pytest.mark.parametrize("threads", ["3", "8"])
+def test_bvh_is_the_same_tree_whatever_the_thread_count(prt, tmp_path, monkeypatch, threads):
+    """the multi-threaded builder (csrc/host/bvh.cpp) claims the tree is a function of the input only: nodes and primitive
+    indices byte for byte against the one-thread build, on a mesh big enough for the thread pool (>= 16 384 triangles)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_make_dragon", os.path.join(ROOT, "scenes", "make_dragon_standin.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    n = mod.write(str(tmp_path / "dragon_standin.prtmesh"), 192, 64)
+    assert n >= 16384
+    text = open(os.path.join(ROOT, "scenes", "cornell_dragon.json")).read()
+
+    def build(k):
+        monkeypatch.setenv("PRT_BVH_THREADS", k)
+        scene = prt.HostScene(text, models_dir=str(tmp_path) + "/", text=True)
+        d = scene.desc
+        return C.string_at(d.bvh_nodes, d.bvh_node_count * 36), C.string_at(d.primitive_indices, d.triangle_count * 8), scene
+
+    nodes1, idx1, _s1 = build("1")
+    nodesk, idxk, _sk = build(threads)
+    assert len(nodes1) > 36 * 1000 and nodes1 == nodesk and idx1 == idxk
 
 
 def test_obj_reader_and_soup_roundtrip(prt, tmp_path):

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """development helper: times the row-block shard one rank of an N-GPU run would render, on ONE GPU, to predict the
 strong-scaling efficiency of bench.py (no collective; the reduce of 33 MB is negligible next to the render)
-usage: shard_time.py [spp=1024]"""
+usage: shard_time.py [spp=1024] [scene=cornell_diffuse.json] [width=1920] [height=1080]
+       (BASELINE config 5: shard_time.py 64 cornell_dragon.json 3840 2160)"""
 import importlib
 import os
 import sys
@@ -12,10 +13,13 @@ sys.path.insert(0, ROOT)
 prt = importlib.import_module("photorealistic-rendering-using-opencl_amd")
 par = importlib.import_module("photorealistic-rendering-using-opencl_amd.parallel")
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-W, H = 1920, 1080
-scene = prt.HostScene("cornell_diffuse.json")
+scene_name = sys.argv[2] if len(sys.argv) > 2 else "cornell_diffuse.json"
+W, H = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (1920, 1080)
+if "dragon" in scene_name:
+    prt.ensure_dragon_standin()
+scene = prt.HostScene(scene_name)
 cfg = scene.config()
-seeds = prt.seed_pairs(spp * 8 + 64)
+seeds = prt.seed_pairs(spp * max(cfg.max_bounces, 8) + 64)
 base = None
 for world in (1, 2, 4, 8):
     worst = 0.0
