@@ -7,7 +7,7 @@
  * one flipped decision (Russian roulette, Fresnel choice, edge hit/miss) desynchronises a pixel
  * for ever, so "same picture as the reference" is only meaningful against ONE stated
  * implementation of those built-ins.  This header is that implementation.  Every function is
- * written with IEEE-754 binary32 +,-,*,/,sqrt,fma and integer operations only, so that it
+ * written with IEEE-754 binary32 (prt_pow: binary64) +,-,*,/,sqrt,fma and integer operations only, so that it
  * produces the same bits on x86-64 (gcc / clang, -ffp-contract=off) and on gfx950 (hipcc,
  * -ffp-contract=off, correctly rounded divide/sqrt which is hipcc's default).
  *
@@ -17,8 +17,9 @@
  *         reference's own kernel text run on the host).
  *
  * Accuracy (tests/test_detmath.py, against float64 libm): sin/cos <= 2 ulp on |x| <= 1e4, tan <= 4 ulp,
- * exp/log <= 2 ulp, acos/atan2 <= 3 ulp, cbrt <= 2 ulp, pow(x,2) exact, general pow <= ~(4+4|y ln x|) ulp.
- * All inside the OpenCL 1.2 full-profile bounds except general pow with huge exponents.
+ * exp/log <= 2 ulp, acos/atan2 <= 3 ulp, cbrt <= 2 ulp, pow(x,2) exact, general pow <= 0.51 ulp (computed in binary64).
+ * All inside the OpenCL 1.2 full-profile bounds.  sin / cos / tan lose accuracy beyond |x| ~ 1e4 (three-constant argument
+ * reduction): the path only passes angles in [0, 2 pi] and half the field of view.
  */
 #ifndef PRT_DETMATH_H
 #define PRT_DETMATH_H
@@ -192,7 +193,14 @@ PRT_HD float prt_log(float x) {
     return prt_fma(fe, LN2_H, prt_fma(fe, LN2_L, lm));
 }
 
-/* ---- pow -------------------------------------------------------------------------------- */
+/* ---- pow --------------------------------------------------------------------------------
+ * General case in IEEE binary64 (+ - * / and integer operations only, like everything here: the same bits on x86-64 and gfx950):
+ * x = 2^e m with m in [sqrt(1/2), sqrt(2)), log2 x = e + log2(e) * 2 atanh((m - 1) / (m + 1)) by its series, t = y log2 x,
+ * 2^t = 2^n exp((t - n) ln 2) by its series, one rounding to binary32 at the end.  The error of t is below 2^-42 of the result's
+ * exponent over the whole range (|t| <= 150), so the result is the correctly rounded one except for results within 2^-18 ulp of
+ * a rounding boundary: at most 0.5 ulp + 4e-6 (measured on a 2^16 x 2^16 lattice of the arguments the Phong lobe produces,
+ * kernels/bxdf/microfacet.cl:31-33,95-97: profiles/r03_detmath_ulp.txt).  Round 1-2 computed exp(y * log x) in binary32, whose
+ * error grows with |y ln x| (tens of ulp for the Phong exponents 2 / r^2 - 2 of small roughness). */
 PRT_HD float prt_pow(float x, float y) {
     if (y == 2.0f) return x * x;                    /* the only form the BASELINE configs use; exact */
     if (y == 0.0f || x == 1.0f) return 1.0f;
@@ -200,7 +208,34 @@ PRT_HD float prt_pow(float x, float y) {
     if (y == 1.0f) return x;
     if (x == 0.0f) return (y > 0.0f) ? 0.0f : prt_u2f(0x7f800000u);
     if (x < 0.0f) return prt_u2f(0x7fc00000u);      /* negative bases are never used by the path */
-    return prt_exp(y * prt_log(x));
+    const float INF = prt_u2f(0x7f800000u);
+    if (x == INF) return (y > 0.0f) ? INF : 0.0f;
+    if (y == INF || y == -INF) return ((x > 1.0f) == (y > 0.0f)) ? INF : 0.0f;
+    unsigned ux = prt_f2u(x);
+    int e = 0;
+    if (ux < 0x00800000u) { ux = prt_f2u(x * 16777216.0f); e = -24; }            /* subnormal base */
+    e += (int)(ux >> 23) - 127;
+    float m = prt_u2f((ux & 0x007fffffu) | 0x3f800000u);                         /* [1, 2) */
+    if (m > 0x1.6a09e6p+0f) { m *= 0.5f; e += 1; }                               /* [sqrt(1/2), sqrt(2)) */
+    const double f = (double)m - 1.0;
+    const double s = f / (2.0 + f), z = s * s;
+    double p = 1.0 / 21.0;                                                      /* atanh s = s (1 + z/3 + z^2/5 + ...), z <= 0.0295 */
+    p = p * z + 1.0 / 19.0; p = p * z + 1.0 / 17.0; p = p * z + 1.0 / 15.0; p = p * z + 1.0 / 13.0; p = p * z + 1.0 / 11.0;
+    p = p * z + 1.0 / 9.0; p = p * z + 1.0 / 7.0; p = p * z + 1.0 / 5.0; p = p * z + 1.0 / 3.0;
+    const double ln_m = 2.0 * s + 2.0 * s * (z * p);
+    const double t = (double)y * ((double)e + ln_m * 0x1.71547652b82fep+0);      /* log2(e) */
+    if (!(t < 128.0)) return INF;
+    if (t < -150.0) return 0.0f;
+    const long long n = (long long)(t + (t >= 0.0 ? 0.5 : -0.5));
+    const double w = (t - (double)n) * 0x1.62e42fefa39efp-1;                     /* ln 2; |w| <= 0.347 */
+    double q = 1.0 / 6227020800.0;                                               /* exp w, degree 13 */
+    q = q * w + 1.0 / 479001600.0; q = q * w + 1.0 / 39916800.0; q = q * w + 1.0 / 3628800.0; q = q * w + 1.0 / 362880.0;
+    q = q * w + 1.0 / 40320.0; q = q * w + 1.0 / 5040.0; q = q * w + 1.0 / 720.0; q = q * w + 1.0 / 120.0; q = q * w + 1.0 / 24.0;
+    q = q * w + 1.0 / 6.0; q = q * w + 0.5; q = q * w + 1.0; q = q * w + 1.0;
+    unsigned long long sb = (unsigned long long)(n + 1023) << 52;                /* 2^n, n in [-150, 128] */
+    double scale;
+    __builtin_memcpy(&scale, &sb, 8);
+    return (float)(q * scale);
 }
 
 /* ---- cbrt (kernels/phasefunctions/Rayleigh.cl:24) ------------------------------------------------------ */

@@ -8,6 +8,7 @@ What gets built
   oracle/_ref/ref_host            reference host code: include/Scene/scene.h (JSON loader),
                                   include/CL/cl_kernel.h (kernel specialiser), Camera
                                   (+ oracle/ref/ref_host.cpp, a 90-line driver)
+  (--math libm: the same with the scalar transcendental built-ins taken from glibc's libm instead of prt_detmath.h)
   oracle/_ref/libref_<variant>.so reference device code: kernels/main.cl and everything it
                                   #FILE-includes, specialised for one scene by the reference's
                                   own cl_kernel.h::parse, compiled as OpenCL C for x86-64 by
@@ -86,12 +87,12 @@ def build_host():
     return exe
 
 
-def build_support(tmp):
+def build_support(tmp, math="detmath"):
     objs = []
     for src in ("clrt_shim.cpp", "ref_harness.cpp"):
         o = os.path.join(tmp, src + ".o")
-        run([CLANGXX, "-std=c++17", "-O2", "-ffp-contract=off", "-Wall", "-Werror", MARCH, "-fPIC", "-I%s/include" % ROOT,
-             "-c", os.path.join(HERE, src), "-o", o])
+        run([CLANGXX, "-std=c++17", "-O2", "-ffp-contract=off", "-Wall", "-Werror", MARCH, "-fPIC", "-I%s/include" % ROOT] +
+            (["-DSHIM_LIBM"] if math == "libm" else []) + ["-c", os.path.join(HERE, src), "-o", o])
         objs.append(o)
     return objs
 
@@ -136,6 +137,9 @@ def main():
     ap.add_argument("--blob-dir", default=os.path.join(ROOT, "tests", "golden"))
     ap.add_argument("--view", default="", choices=["", "VIEW_NORMAL", "VIEW_ALBEDO", "VIEW_SPECULAR", "VIEW_BVH_HIT"],
                     help="debug view of kernels/main.cl:6-15 (VIEW_STACK_INDEX does not compile: Ray has no bvh_stackIndex)")
+    ap.add_argument("--math", default="detmath", choices=["detmath", "libm"],
+                    help="the OpenCL built-in library behind the kernel text: include/prt_detmath.h (the stated one) or, for the scalar "
+                         "transcendentals, the GNU C library's libm (the independent flavour, tools/independent_math.py)")
     ap.add_argument("--kat", action="store_true", help="append oracle/ref/kat_harness.cl (per-function known-answer entry point kat_run)")
     a = ap.parse_args()
     if not os.path.isdir(REF):
@@ -145,7 +149,7 @@ def main():
     tmp = tempfile.mkdtemp(prefix="prt_ref_")
     try:
         make_farm(tmp)
-        support = build_support(tmp)
+        support = build_support(tmp, a.math)
         set_phase(tmp, a.phase)
         for v in a.variant:
             name, scene = v.split("=", 1)

@@ -10,6 +10,13 @@
 //                              CLK_NORMALIZED_COORDS_TRUE | CLK_ADDRESS_CLAMP | CLK_FILTER_LINEAR)
 //   * math / geometric         every one in terms of include/prt_detmath.h, the numerics
 //                              contract of the C-ABI (see that header for why).
+//                              -DSHIM_LIBM (build_ref.py --math libm): the second flavour -- the scalar
+//                              transcendental built-ins (sin cos tan acos atan2 exp log pow cbrt and their
+//                              native_ forms) forward to the GNU C library's libm instead: math this repository
+//                              did not write.  Pictures of the two flavours differ in individual decisions
+//                              (a path tracer is chaotic) but must agree as estimates: tools/independent_math.py,
+//                              tests/test_oracle.py.  The exactly rounded operations (sqrt, divide, fma, fmin /
+//                              fmax, rounding) and the geometric / image functions are the same in both.
 // Vector forms are component-wise; dot/cross/length/normalize evaluate left to right with one
 // rounding per operation (no fma), which is also what oracle/pt_oracle.c and the HIP kernels do.
 //
@@ -18,6 +25,31 @@
 #include <cstring>
 #include <cstdint>
 #include "prt_detmath.h"
+
+#ifdef SHIM_LIBM
+// (declared here rather than through <math.h>, whose C++ overloads would collide with the built-ins this file defines)
+extern "C" { float sinf(float); float cosf(float); float tanf(float); float acosf(float); float atan2f(float, float);
+             float expf(float); float logf(float); float powf(float, float); float cbrtf(float); }
+#define T_SIN(x) ::sinf(x)
+#define T_COS(x) ::cosf(x)
+#define T_TAN(x) ::tanf(x)
+#define T_ACOS(x) ::acosf(x)
+#define T_ATAN2(y, x) ::atan2f(y, x)
+#define T_EXP(x) ::expf(x)
+#define T_LOG(x) ::logf(x)
+#define T_POW(x, y) ::powf(x, y)
+#define T_CBRT(x) ::cbrtf(x)
+#else
+#define T_SIN(x) prt_sin(x)
+#define T_COS(x) prt_cos(x)
+#define T_TAN(x) prt_tan(x)
+#define T_ACOS(x) prt_acos(x)
+#define T_ATAN2(y, x) prt_atan2(y, x)
+#define T_EXP(x) prt_exp(x)
+#define T_LOG(x) prt_log(x)
+#define T_POW(x, y) prt_pow(x, y)
+#define T_CBRT(x) prt_cbrt(x)
+#endif
 
 typedef float float2 __attribute__((ext_vector_type(2)));
 typedef float float3 __attribute__((ext_vector_type(3)));
@@ -65,14 +97,14 @@ void shim_write_imagef(ShimImage* im, int2 c, float4 v) {
 }
 
 // ---- scalar math ---------------------------------------------------------------------------
-float sin(float x) { return prt_sin(x); }
-float cos(float x) { return prt_cos(x); }
-float tan(float x) { return prt_tan(x); }
-float acos(float x) { return prt_acos(x); }
-float atan2(float y, float x) { return prt_atan2(y, x); }
-float exp(float x) { return prt_exp(x); }
-float log(float x) { return prt_log(x); }
-float pow(float x, float y) { return prt_pow(x, y); }
+float sin(float x) { return T_SIN(x); }
+float cos(float x) { return T_COS(x); }
+float tan(float x) { return T_TAN(x); }
+float acos(float x) { return T_ACOS(x); }
+float atan2(float y, float x) { return T_ATAN2(y, x); }
+float exp(float x) { return T_EXP(x); }
+float log(float x) { return T_LOG(x); }
+float pow(float x, float y) { return T_POW(x, y); }
 float sqrt(float x) { return prt_sqrt(x); }
 float fabs(float x) { return prt_fabs(x); }
 float fmin(float a, float b) { return prt_fmin(a, b); }
@@ -81,20 +113,20 @@ float fma(float a, float b, float c) { return prt_fma(a, b, c); }
 float mix(float a, float b, float t) { return prt_mix(a, b, t); }
 float round(float x) { return prt_round(x); }
 float copysign(float x, float s) { return prt_copysign(x, s); }
-float native_sin(float x) { return prt_sin(x); }
-float native_cos(float x) { return prt_cos(x); }
-float native_exp(float x) { return prt_exp(x); }
-float native_log(float x) { return prt_log(x); }
+float native_sin(float x) { return T_SIN(x); }
+float native_cos(float x) { return T_COS(x); }
+float native_exp(float x) { return T_EXP(x); }
+float native_log(float x) { return T_LOG(x); }
 float native_sqrt(float x) { return prt_sqrt(x); }
-float cbrt(float x) { return prt_cbrt(x); }
+float cbrt(float x) { return T_CBRT(x); }
 float native_recip(float x) { return prt_recip(x); }
 float shim_fract1(float x, float* ip) __asm__("_Z5fractfPU9CLprivatef");
 float shim_fract1(float x, float* ip) { *ip = prt_floor(x); return prt_fract(x); }
 
 // ---- float3 forms --------------------------------------------------------------------------
 #define V3(fn) float3{fn(v.x), fn(v.y), fn(v.z)}
-float3 exp(float3 v) { return V3(prt_exp); }
-float3 native_exp(float3 v) { return V3(prt_exp); }
+float3 exp(float3 v) { return float3{T_EXP(v.x), T_EXP(v.y), T_EXP(v.z)}; }
+float3 native_exp(float3 v) { return float3{T_EXP(v.x), T_EXP(v.y), T_EXP(v.z)}; }
 float3 native_recip(float3 v) { return V3(prt_recip); }
 float3 fmin(float3 a, float3 b) { return float3{prt_fmin(a.x, b.x), prt_fmin(a.y, b.y), prt_fmin(a.z, b.z)}; }
 float3 fmax(float3 a, float3 b) { return float3{prt_fmax(a.x, b.x), prt_fmax(a.y, b.y), prt_fmax(a.z, b.z)}; }

@@ -2,7 +2,8 @@
  * inputs against the float64 libm, on the CPU (the GPU gives the same bits: tests/test_detmath.py).  Prints, per
  * function and domain, the largest error in units of the last place of the correctly rounded result and where it occurs.
  *   gcc -O2 -ffp-contract=off -march=x86-64-v3 -Iinclude -o /tmp/detmath_sweep tools/detmath_sweep.c -lm -lpthread
- *   /tmp/detmath_sweep > profiles/r02_detmath_ulp.txt                       (about five minutes on 8 cores) */
+ * and the two-argument ones (atan2, pow) on 2^16 x 2^16 lattices of the argument ranges the path produces.
+ *   /tmp/detmath_sweep > profiles/r03_detmath_ulp.txt                       (about ten minutes on 8 cores) */
 #include <math.h>
 #include <pthread.h>
 #include <stdint.h>
@@ -80,6 +81,53 @@ static void* work(void* arg) {
     return 0;
 }
 
+/* ---- two-argument functions: 2^16 x 2^16 lattices of the ranges the radiance loop passes ------------------------------- */
+typedef struct { const char* name; const char* domain; int kind; } Case2;
+static const Case2 CASES2[] = {
+    {"prt_atan2(y, x)", "x, y on a lattice of [-1, 1]^2 (utils.cl:46 envMapEquirect: atan2(dir.z, dir.x))", 0},
+    {"prt_atan2(y, x)", "|x|, |y| = 2^a, a on a lattice of [-40, 20], all four sign pairs", 1},
+    {"prt_pow(c, alpha)", "c on a lattice of (0, 1], alpha = 2 / r^2 - 2, r on a lattice of [1e-3, 1] (microfacet.cl:31-33 Phong D)", 2},
+    {"prt_pow(xi, 1 / (alpha + 2))", "xi on a lattice of (0, 1), alpha as above (microfacet.cl:95-97 Phong sample)", 3},
+    {"prt_pow(v, 1 / 2.2)", "v on a lattice of [0, 1] x 2^16 sub-steps (shaders/tonemapper.glsl gamma)", 4},
+};
+typedef struct { const Case2* c; int tid; double max_ulp; float ax, ay; uint64_t n; } Job2;
+static void* work2(void* arg) {
+    Job2* j = (Job2*)arg;
+    j->max_ulp = 0; j->n = 0; j->ax = j->ay = 0;
+    for (int i = j->tid; i < 65536; i += NT)
+        for (int k = 0; k < 65536; ++k) {
+            float x, y, got; double want;
+            const float u = ((float)i + 0.5f) / 65536.0f, v = ((float)k + 0.5f) / 65536.0f;
+            switch (j->c->kind) {
+                case 0: x = 2.0f * u - 1.0f; y = 2.0f * v - 1.0f; got = prt_atan2(y, x); want = atan2((double)y, (double)x); break;
+                case 1: { const int sg = (i & 1) | ((k & 1) << 1);
+                          x = exp2f(-40.0f + 60.0f * u); y = exp2f(-40.0f + 60.0f * v); if (sg & 1) x = -x; if (sg & 2) y = -y;
+                          got = prt_atan2(y, x); want = atan2((double)y, (double)x); break; }
+                case 2: { const float r = 1e-3f + (1.0f - 1e-3f) * v; x = u; y = 2.0f / (r * r) - 2.0f; if (y == 2.0f) continue;
+                          got = prt_pow(x, y); want = pow((double)x, (double)y); break; }
+                case 3: { const float r = 1e-3f + (1.0f - 1e-3f) * v; x = u; y = 1.0f / ((2.0f / (r * r) - 2.0f) + 2.0f);
+                          got = prt_pow(x, y); want = pow((double)x, (double)y); break; }
+                default: x = u + v / 65536.0f; y = 1.0f / 2.2f; got = prt_pow(x, y); want = pow((double)x, (double)y); break;
+            }
+            if (want != 0.0 && fabs(want) < 1.1754944e-38) continue;            /* subnormal results are not priced */
+            const double err = ulp_err(got, want);
+            ++j->n;
+            if (err > j->max_ulp) { j->max_ulp = err; j->ax = x; j->ay = y; }
+        }
+    printf("\ntwo-argument functions, 2^16 x 2^16 lattices of the argument ranges the path produces, against float64 libm\n");
+    printf("%-30s %14s %10s  %-28s %s\n", "function", "pairs", "max ulp", "at (first, second argument)", "domain");
+    for (unsigned k = 0; k < sizeof(CASES2) / sizeof(CASES2[0]); ++k) {
+        pthread_t th[NT];
+        Job2 jobs[NT];
+        for (int t = 0; t < NT; ++t) { jobs[t].c = &CASES2[k]; jobs[t].tid = t; pthread_create(&th[t], 0, work2, &jobs[t]); }
+        double mx = 0; float ax = 0, ay = 0; uint64_t n = 0;
+        for (int t = 0; t < NT; ++t) { pthread_join(th[t], 0); n += jobs[t].n; if (jobs[t].max_ulp > mx) { mx = jobs[t].max_ulp; ax = jobs[t].ax; ay = jobs[t].ay; } }
+        printf("%-30s %14llu %10.4f  (%-13a, %-13a) %s\n", CASES2[k].name, (unsigned long long)n, mx, ax, ay, CASES2[k].domain);
+        fflush(stdout);
+    }
+    return 0;
+}
+
 int main(void) {
     printf("include/prt_detmath.h, one-argument functions, every binary32 input of the domain, against float64 libm (CPU, x86-64)\n");
     printf("%-18s %-34s %14s %12s %12s  %s\n", "function", "domain", "inputs", "max ulp", "at (bits)", "note");
@@ -92,6 +140,28 @@ int main(void) {
         char note[96] = "";
         if (CASES[k].exact) snprintf(note, sizeof note, "must be correctly rounded: %llu inputs are not", (unsigned long long)wrong);
         printf("%-18s %-34s %14llu %12.4f   0x%08x  %s\n", CASES[k].name, CASES[k].domain, (unsigned long long)n, mx, at, note);
+        fflush(stdout);
+    }
+    printf("\ntwo-argument functions, 2^16 x 2^16 lattices of the argument ranges the path produces, against float64 libm\n");
+    printf("%-30s %14s %10s  %-28s %s\n", "function", "pairs", "max ulp", "at (first, second argument)", "domain");
+    for (unsigned k = 0; k < sizeof(CASES2) / sizeof(CASES2[0]); ++k) {
+        pthread_t th[NT];
+        Job2 jobs[NT];
+        for (int t = 0; t < NT; ++t) { jobs[t].c = &CASES2[k]; jobs[t].tid = t; pthread_create(&th[t], 0, work2, &jobs[t]); }
+        double mx = 0; float ax = 0, ay = 0; uint64_t n = 0;
+        for (int t = 0; t < NT; ++t) { pthread_join(th[t], 0); n += jobs[t].n; if (jobs[t].max_ulp > mx) { mx = jobs[t].max_ulp; ax = jobs[t].ax; ay = jobs[t].ay; } }
+        printf("%-30s %14llu %10.4f  (%-13a, %-13a) %s\n", CASES2[k].name, (unsigned long long)n, mx, ax, ay, CASES2[k].domain);
+        fflush(stdout);
+    }
+    printf("\ntwo-argument functions, 2^16 x 2^16 lattices of the argument ranges the path produces, against float64 libm\n");
+    printf("%-30s %14s %10s  %-28s %s\n", "function", "pairs", "max ulp", "at (first, second argument)", "domain");
+    for (unsigned k = 0; k < sizeof(CASES2) / sizeof(CASES2[0]); ++k) {
+        pthread_t th[NT];
+        Job2 jobs[NT];
+        for (int t = 0; t < NT; ++t) { jobs[t].c = &CASES2[k]; jobs[t].tid = t; pthread_create(&th[t], 0, work2, &jobs[t]); }
+        double mx = 0; float ax = 0, ay = 0; uint64_t n = 0;
+        for (int t = 0; t < NT; ++t) { pthread_join(th[t], 0); n += jobs[t].n; if (jobs[t].max_ulp > mx) { mx = jobs[t].max_ulp; ax = jobs[t].ax; ay = jobs[t].ay; } }
+        printf("%-30s %14llu %10.4f  (%-13a, %-13a) %s\n", CASES2[k].name, (unsigned long long)n, mx, ax, ay, CASES2[k].domain);
         fflush(stdout);
     }
     return 0;
