@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PRT_ABI_VERSION 2
+#define PRT_ABI_VERSION 3
 #define PRT_MAX_LIGHTS 16
 
 typedef enum prt_status {
@@ -63,7 +63,7 @@ typedef struct prt_config {
     uint32_t active_mats;            /* :226-345  ACTIVE_MATS: OR of all material type bits in the scene */
     uint32_t geom_flags;             /* :180-222  PRT_GEOM_* bits for H_SPHERE/H_BOX/H_SDF/H_QUAD */
     uint32_t light_count;            /* :367-400  LIGHT_COUNT */
-    uint32_t light_indices[PRT_MAX_LIGHTS]; /*   LIGHT_INDICES (only [0] is ever sampled, base.cl:92) */
+    uint32_t light_indices[PRT_MAX_LIGHTS]; /*   LIGHT_INDICES (only [0] is ever sampled, base.cl:92 -- unless pick_random_light) */
     int32_t has_global_medium;       /* :47-54    GLOBAL_MEDIUM */
     float fog_density;               /* :66-75    values AFTER the "%f" round trip of std::to_string */
     float fog_sigma_a;               /* :77-84 */
@@ -78,6 +78,12 @@ typedef struct prt_config {
                                       * accumulator itself (main.cl:143-145,150-152,161).  The other values of the reference's list are
                                       * refused: VIEW_STACK_INDEX does not compile there (Ray has no bvh_stackIndex), VIEW_ALBEDO and
                                       * VIEW_SPECULAR have no branch at all -- radiance() is never called and the image stays black */
+    uint32_t pick_random_light;      /* kernels/integrators/base.cl:9 PICK_RANDOM_LIGHT (a source-level `#define ... 0` in the reference): 1 = the
+                                      * light of lightSample / volumeLightSample is LIGHT_INDICES[(int)(next1D() * (LIGHT_COUNT + 1))]
+                                      * (base.cl:88-90,202-204) -- one draw more per light sample, and an index one PAST the array with
+                                      * probability 1 / (LIGHT_COUNT + 1).  That entry is defined here as 0 (mesh 0 is sampled as if it were
+                                      * a light), which is what the reference build of the fixtures reads there (the array is declared one
+                                      * element longer in the temporary text: zero-initialised).  Needs light_count < PRT_MAX_LIGHTS. */
 } prt_config;
 
 /* Host buffers of one scene, in the reference's layouts (src/main.cpp:93-122,401-418). */

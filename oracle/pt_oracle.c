@@ -1067,8 +1067,17 @@ static v3 bsdfSample(Scene* sc, SurfaceScatterEvent* e, Ray* ray, int has_medium
     return vsplat(0.0f);
 }
 
+/* base.cl:88-93 / :202-207: LIGHT_INDICES[0], or -- PICK_RANDOM_LIGHT, a source-level switch of the reference, prt_config::pick_random_light
+ * here -- LIGHT_INDICES[(int)(next1D() * (LIGHT_COUNT + 1))]: one past the array with probability 1 / (LIGHT_COUNT + 1); that entry is 0
+ * (include/prt.h; the reference build of the fixtures declares the array one element longer) */
+static const prt_mesh* pick_light(Scene* sc, Rng* rng) {
+    if (!sc->cfg->pick_random_light) return &sc->meshes[sc->cfg->light_indices[0]];
+    const int k = (int)(next1D(rng) * (float)(sc->cfg->light_count + 1));
+    return &sc->meshes[(uint32_t)k < sc->cfg->light_count ? sc->cfg->light_indices[k] : 0u];
+}
+
 static v3 lightSample(Scene* sc, SurfaceScatterEvent* e, const Ray* ray, int has_medium, const prt_material* mat, Rng* rng) {  /* :79-134 */
-    const prt_mesh* light = &sc->meshes[sc->cfg->light_indices[0]];
+    const prt_mesh* light = pick_light(sc, rng);
     LightSample rec;
     if (!sampleDirect(sc, light, ray->pos, &rec, rng)) return vsplat(0.0f);
     e->wo = toLocal(&e->frame, rec.d);
@@ -1108,7 +1117,7 @@ static int handleSurface(Scene* sc, SurfaceScatterEvent* e, Ray* ray, int has_me
 }
 
 static v3 volumeLightSample(Scene* sc, const MediumSample* ms, const Ray* ray, Rng* rng) {      /* :194-230 */
-    const prt_mesh* light = &sc->meshes[sc->cfg->light_indices[0]];
+    const prt_mesh* light = pick_light(sc, rng);
     LightSample rec;
     if (!sampleDirect(sc, light, ray->pos, &rec, rng)) return vsplat(0.0f);     /* ray->pos, not ms->p (Q4) */
     v3 f = phase_eval(sc, ray->dir, rec.d);

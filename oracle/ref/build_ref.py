@@ -24,6 +24,8 @@ Known, documented interventions:
       42-44,97): `--shadow-stack N` rewrites that one `#define STACK_SIZE 8` in the TEMP text so
       the host run cannot smash its stack.  Results are identical whenever the original would
       not have overflowed.
+  PICK_RANDOM_LIGHT (kernels/integrators/base.cl:9) is a source-level switch whose code reads one element past LIGHT_INDICES:
+      `--pick-random-light` flips it in the TEMP text and declares the array one (zero-initialised) element longer.
   C99 `inline` functions without an external definition (kernels/bxdf/Fresnel.cl:33) are
       compiled with -Dinline= so they get one.
 """
@@ -97,13 +99,20 @@ def build_support(tmp, math="detmath"):
     return objs
 
 
-def build_variant(name, scene, width, height, alpha, shadow_stack, phase, blob_dir, exe, tmp, support, kat=False, view=""):
+def build_variant(name, scene, width, height, alpha, shadow_stack, phase, blob_dir, exe, tmp, support, kat=False, view="", pick=False):
     cl = os.path.join(tmp, name + ".cl")
     blob = os.path.join(blob_dir, name + ".sceneblob")
     run([exe, os.path.abspath(scene), str(width), str(height), "1" if alpha else "0", cl, blob],
         cwd=os.path.join(tmp, "run"))
-    if shadow_stack or kat or view:
+    if shadow_stack or kat or view or pick:
         text = open(cl).read()
+        if pick:    # PICK_RANDOM_LIGHT is a source-level switch (kernels/integrators/base.cl:9).  Switched on it indexes LIGHT_INDICES one
+                    # past its end with probability 1 / (LIGHT_COUNT + 1) (base.cl:90,204): the array gets one more, zero-initialised,
+                    # element in the temp text, so that what is read there is defined (include/prt.h prt_config::pick_random_light)
+            for needle, repl in (("#define PICK_RANDOM_LIGHT 0", "#define PICK_RANDOM_LIGHT 1"),
+                                 ("__constant uint LIGHT_INDICES[LIGHT_COUNT] = {", "__constant uint LIGHT_INDICES[LIGHT_COUNT + 1] = {")):
+                assert text.count(needle) >= 1, "%r not found" % needle     # (header.cl is spliced in more than once, behind its include guard)
+                text = text.replace(needle, repl)
         if view:    # the debug views are a source-level switch of kernels/main.cl:15 (VIEW_OPTION ... & VIEW_RESULTS): flip it in the temp text
             needle = "#define VIEW_OPTION (~(0xFF<<(DEBUG*8)) & VIEW_RESULTS)"
             assert text.count(needle) == 1, "VIEW_OPTION define not found exactly once"
@@ -140,6 +149,7 @@ def main():
     ap.add_argument("--math", default="detmath", choices=["detmath", "libm"],
                     help="the OpenCL built-in library behind the kernel text: include/prt_detmath.h (the stated one) or, for the scalar "
                          "transcendentals, the GNU C library's libm (the independent flavour, tools/independent_math.py)")
+    ap.add_argument("--pick-random-light", action="store_true", help="PICK_RANDOM_LIGHT 1 (kernels/integrators/base.cl:9) with a defined entry behind LIGHT_INDICES")
     ap.add_argument("--kat", action="store_true", help="append oracle/ref/kat_harness.cl (per-function known-answer entry point kat_run)")
     a = ap.parse_args()
     if not os.path.isdir(REF):
@@ -154,7 +164,7 @@ def main():
         for v in a.variant:
             name, scene = v.split("=", 1)
             so = build_variant(name, scene, a.width, a.height, a.alpha, a.shadow_stack, a.phase,
-                               a.blob_dir, exe, tmp, support, kat=a.kat, view=a.view)
+                               a.blob_dir, exe, tmp, support, kat=a.kat, view=a.view, pick=a.pick_random_light)
             print("built", so)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PRT_LIB", os.path.join(HERE, "libprt.so"))   # PRT_LIB: A/B builds of the same product
 
 PRT_MAX_LIGHTS = 16
-PRT_ABI_VERSION = 2
+PRT_ABI_VERSION = 3
 
 
 class Material(C.Structure):
@@ -46,7 +46,7 @@ class Config(C.Structure):
                 ("has_global_medium", C.c_int32), ("fog_density", C.c_float), ("fog_sigma_a", C.c_float),
                 ("fog_sigma_s", C.c_float), ("fog_sigma_t", C.c_float), ("fog_abs_only", C.c_int32),
                 ("alpha_testing", C.c_int32), ("phase_function", C.c_int32), ("phase_g", C.c_float),
-                ("view_option", C.c_uint32)]
+                ("view_option", C.c_uint32), ("pick_random_light", C.c_uint32)]
 
 
 class SceneDesc(C.Structure):

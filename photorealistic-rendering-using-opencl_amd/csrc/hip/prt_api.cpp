@@ -32,7 +32,7 @@ struct prt_ctx {
     // scene
     DevScene sc{};
     void* d_pairs = nullptr; void* d_tri_geom = nullptr; void* d_tri_nrm = nullptr;
-    void* d_spheres = nullptr; void* d_quads = nullptr; void* d_sdfs = nullptr; void* d_mats = nullptr; void* d_env = nullptr;
+    void* d_spheres = nullptr; void* d_quads = nullptr; void* d_sdfs = nullptr; void* d_mats = nullptr; void* d_light_tab = nullptr; void* d_env = nullptr;
     bool have_scene = false, have_cam = false, have_size = false;
     bool state_undefined = false;   // a render call failed half-way (prt_render_spp's abort path): pixels may be ahead of the launch windows
                                     // (run-ahead leads in the state) -- the state is unusable until prt_reset / prt_write_state
@@ -150,7 +150,7 @@ static void free_frame(prt_ctx* c) {
 }
 static void free_scene(prt_ctx* c) {
     free_dev(c->d_pairs); free_dev(c->d_tri_geom); free_dev(c->d_tri_nrm);
-    free_dev(c->d_spheres); free_dev(c->d_quads); free_dev(c->d_sdfs); free_dev(c->d_mats);
+    free_dev(c->d_spheres); free_dev(c->d_quads); free_dev(c->d_sdfs); free_dev(c->d_mats); free_dev(c->d_light_tab);
 }
 
 extern "C" void prt_destroy(prt_ctx* c) {
@@ -205,7 +205,7 @@ extern "C" int prt_upload_scene(prt_ctx* c, const prt_scene_desc* s) {
     c->sc.env = env; c->sc.env_w = env_w; c->sc.env_h = env_h;
     if ((rc = upload(c, c->d_pairs, ps.pairs)) || (rc = upload(c, c->d_tri_geom, ps.tg)) || (rc = upload(c, c->d_tri_nrm, ps.tn)) ||
         (rc = upload(c, c->d_spheres, ps.spheres)) || (rc = upload(c, c->d_quads, ps.quads)) || (rc = upload(c, c->d_sdfs, ps.sdfs)) ||
-        (rc = upload(c, c->d_mats, ps.mats)))
+        (rc = upload(c, c->d_mats, ps.mats)) || (rc = upload(c, c->d_light_tab, ps.light_tab)))
         return rc;
     DevScene sc = ps.sc;
     sc.pairs = static_cast<const NodePair*>(c->d_pairs);
@@ -215,6 +215,7 @@ extern "C" int prt_upload_scene(prt_ctx* c, const prt_scene_desc* s) {
     sc.quads = static_cast<const DevQuad*>(c->d_quads);
     sc.sdfs = static_cast<const DevSdf*>(c->d_sdfs);
     sc.mats = static_cast<const DevMaterial*>(c->d_mats);
+    sc.light_tab = static_cast<const uint32_t*>(c->d_light_tab);
     sc.env = env; sc.env_w = env_w; sc.env_h = env_h;
     c->sc = sc;
     if (!c->sc.env) {

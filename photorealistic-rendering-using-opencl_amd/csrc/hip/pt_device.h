@@ -659,6 +659,17 @@ PT_DEV bool sample_light0(const DevScene& sc, f3 p, LightSample& ls, Rng& rng) {
     if (sc.light_quad != 0xFFFFFFFFu) return quad_sample_direct(sc.quads[sc.light_quad], p, ls, rng);
     return false;
 }
+// the light of lightSample / volumeLightSample (base.cl:88-93,202-207) and its sample: LIGHT_INDICES[0], or -- PICK: the reference's
+// PICK_RANDOM_LIGHT, prt_config::pick_random_light -- LIGHT_INDICES[(int)(next1D() * (LIGHT_COUNT + 1))], the draw BEFORE the sampler's own
+// (the entry behind the array is in the table: DevScene::light_tab).  `mesh`: whose colour the contribution carries.
+PT_DEV bool sample_light(const DevScene& sc, const bool PICK, f3 p, LightSample& ls, Rng& rng, unsigned& mesh) {
+    if (!PICK) { mesh = sc.light_mesh; return sample_light0(sc, p, ls, rng); }
+    const int k = (int)(next1D(rng) * (float)(sc.light_count + 1u));
+    mesh = sc.light_tab[k];
+    if ((sc.geom_flags & PRT_GEOM_SPHERE) && mesh < sc.n_spheres) return sphere_sample_direct(sc.spheres[mesh], p, ls, rng);
+    if ((sc.geom_flags & PRT_GEOM_QUAD) && mesh >= sc.quad_mesh_base) return quad_sample_direct(sc.quads[mesh - sc.quad_mesh_base], p, ls, rng);
+    return false;                                    // geometry.cl:11-32: only spheres and quads can be sampled
+}
 
 // ---- Fresnel, kernels/bxdf/Fresnel.cl:6-67 ----------------------------------------------------------
 PT_DEV float conductor_reflectance(float eta, float k, float cosThetaI) {
@@ -1014,7 +1025,9 @@ PT_DEV float coat_pdf(const Event& e, const Mat& mat) {
 #define PT_MATS_SDF 0x80000000u
 // PT_MATS_VIEW bit: the debug views VIEW_NORMAL / VIEW_BVH_HIT of kernels/main.cl:6-15,143-152 (prt_config::view_option)
 #define PT_MATS_VIEW 0x40000000u
-#define PT_MATS_FLAGS (PT_MATS_SDF | PT_MATS_VIEW)
+// PT_MATS_PICK bit: PICK_RANDOM_LIGHT of kernels/integrators/base.cl:9 (prt_config::pick_random_light)
+#define PT_MATS_PICK 0x20000000u
+#define PT_MATS_FLAGS (PT_MATS_SDF | PT_MATS_VIEW | PT_MATS_PICK)
 template <unsigned MATS>
 PT_DEV unsigned active_mats(const DevScene& sc) { return (MATS & ~PT_MATS_FLAGS) ? (MATS & ~PT_MATS_FLAGS) : sc.active_mats; }
 
@@ -1378,12 +1391,13 @@ PT_DEV void lane_front(const DevScene& sc, const DevCamera& cam, const FrameArgs
             L.wasSpecular = false;
             // volumeLightSample, base.cl:194-230 (samples the light from ray.pos, not ms.p: SURVEY s9-Q4)
             LightSample rec;
-            if (sample_light0(sc, ray.pos, rec, L.rng)) {
+            unsigned lmesh;
+            if (sample_light(sc, (MATS & PT_MATS_PICK) != 0, ray.pos, rec, L.rng, lmesh)) {
                 const float fv = phase_value(sc, ray.dir, rec.d);
                 const f3 f = splat(fv);
                 if (!(dot(f, f) == 0.0f)) {
                     L.sh = true; L.sh_d = rec.d; L.sh_tmax = rec.dist;
-                    const Mat lm = load_mat(&sc.mats[sc.light_mesh + 1]);
+                    const Mat lm = load_mat(&sc.mats[lmesh + 1]);
                     const f3 tr = vexp(splat(sc.fog_sigma_t) * (-1.0f * rec.dist));
                     const f3 contribution = tr * lm.color * f * power_heuristic(rec.pdf, fv);
                     L.vis = contribution / rec.pdf;
@@ -1485,7 +1499,8 @@ PT_DEV void lane_back(const DevScene& sc, Lane& L) {
         }
         // lightSample, base.cl:79-134 (from ray.pos = the probe ray's hit point: SURVEY s9-Q4)
         LightSample rec;
-        if (sample_light0(sc, hit_pos, rec, L.rng)) {
+        unsigned lmesh;
+        if (sample_light(sc, (MATS & PT_MATS_PICK) != 0, hit_pos, rec, L.rng, lmesh)) {
             Event e;
             e.frame = make_frame(L.n_shade);
             e.wi = L.wi; e.weight = L.weight; e.pdf = L.pdf; e.sampledLobe = L.sampledLobe;
@@ -1493,7 +1508,7 @@ PT_DEV void lane_back(const DevScene& sc, Lane& L) {
             const f3 fr = bsdf_eval2<MATS>(sc, e, mat);
             if (!(dot(fr, fr) == 0.0f)) {
                 L.sh = true; L.sh_d = rec.d; L.sh_tmax = rec.dist;
-                const Mat lm = load_mat(&sc.mats[sc.light_mesh + 1]);
+                const Mat lm = load_mat(&sc.mats[lmesh + 1]);
                 f3 contribution = lm.color * fr;
                 if (MEDIUM) contribution = contribution * vexp(splat(sc.fog_sigma_t) * (-1.0f * rec.dist));
                 contribution = contribution * power_heuristic(rec.pdf, bsdf_pdf<MATS>(sc, e, mat));

@@ -31,6 +31,7 @@ PT_DECLARE_SET(launch_set_generic);
 PT_DECLARE_SET(launch_set_sdf);
 PT_DECLARE_SET(launch_set_view);
 PT_DECLARE_SET(launch_set_view_sdf);
+PT_DECLARE_SET(launch_set_pick);
 // workgroups (tiles) launch_render uses for a width x rows frame part
 unsigned render_tile_count(int width, int rows);
 #ifdef PT_PHASE_CLOCKS

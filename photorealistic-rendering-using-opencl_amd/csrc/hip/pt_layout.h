@@ -91,6 +91,10 @@ struct DevScene {
     uint32_t light_sphere;          // LIGHT_INDICES[0] as index into spheres, or 0xFFFFFFFF
     uint32_t light_quad;            // ... as index into quads, or 0xFFFFFFFF
     uint32_t light_mesh;            // LIGHT_INDICES[0]
+    // prt_config::pick_random_light (base.cl:9 PICK_RANDOM_LIGHT; the PT_MATS_PICK kernel variants): mesh index per entry of LIGHT_INDICES
+    // and, at [light_count], of the entry behind it (0)
+    const uint32_t* light_tab;
+    uint32_t light_count, pick_random_light;
     // prt_config
     uint32_t active_mats, geom_flags;
     int max_bounces, max_diff_bounces, max_spec_bounces, max_trans_bounces, max_scattering_events;

@@ -190,6 +190,18 @@ int pack_scene(const prt_config& cfg, const prt_scene_desc* s, PackedScene& out,
     sc.n_spheres = n_sph; sc.n_quads = n_quad; sc.quad_mesh_base = n_sph + n_sdf; sc.n_meshes = n_mesh; sc.n_sdfs = n_sdf;
     sc.marching_steps = cfg.marching_steps; sc.shadow_marching_steps = cfg.shadow_marching_steps;
     sc.light_sphere = sc.light_quad = 0xFFFFFFFFu; sc.light_mesh = 0;
+    sc.light_count = cfg.light_count; sc.pick_random_light = cfg.pick_random_light ? 1u : 0u;
+    out.light_tab.assign(cfg.light_count + 1u, 0u);             // [light_count]: the entry behind LIGHT_INDICES (include/prt.h)
+    for (uint32_t k = 0; k < cfg.light_count && k < PRT_MAX_LIGHTS; ++k) {
+        if (cfg.light_indices[k] >= n_mesh) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: light index out of range");
+        out.light_tab[k] = cfg.light_indices[k];
+    }
+    if (cfg.pick_random_light) {
+        if (!n_mesh) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: pick_random_light without a mesh");
+        if (cfg.light_count >= PRT_MAX_LIGHTS) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: pick_random_light needs light_count < PRT_MAX_LIGHTS");
+        if (n_sdf || cfg.view_option != PRT_VIEW_RESULTS)
+            return fail(c, PRT_ERR_UNSUPPORTED, "prt_upload_scene: pick_random_light is not built together with SDF primitives or a debug view");
+    }
     if (cfg.light_count) {
         const uint32_t li = cfg.light_indices[0];
         if (li >= n_mesh) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: light index out of range");

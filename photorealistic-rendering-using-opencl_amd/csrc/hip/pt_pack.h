@@ -18,6 +18,7 @@ struct PackedScene {
     std::vector<DevQuad> quads;
     std::vector<DevSdf> sdfs;
     std::vector<DevMaterial> mats;
+    std::vector<uint32_t> light_tab;     // DevScene::light_tab
     DevScene sc{};             // every scalar field; the pointers (and env) are filled in by whoever owns the memory
 };
 

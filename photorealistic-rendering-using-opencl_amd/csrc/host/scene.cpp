@@ -236,6 +236,7 @@ prt_config host_scene::make_config(bool alpha_testing) const {
     c.phase_function = PRT_PHASE_ISOTROPIC;       // kernels/media.cl:61
     c.phase_g = 0.6f;                             // kernels/phasefunctions/HenyeyGreenstein.cl:4
     c.view_option = PRT_VIEW_RESULTS;             // kernels/main.cl:15
+    c.pick_random_light = 0;                      // kernels/integrators/base.cl:9
     return c;
 }
 

@@ -113,6 +113,22 @@ SCENES["kat_all"] = cornell({"color": WHITE, "type": 4, "roughness": 0.1},
                                            {"pos": [1.2, 1.3, 0.5], "radius": 0.4, "material": {"color": WHITE, "type": 11, "dist": 1, "roughness": 0.2}}],
                             medium={"density": 0.07, "sigmaA": 0.1, "sigmaS": 1.0})
 
+# two lights -- a sphere and a quad -- behind a non-emitting sphere at mesh index 0: PICK_RANDOM_LIGHT (kernels/integrators/base.cl:9,88-93;
+# prt_config::pick_random_light) picks LIGHT_INDICES[0], LIGHT_INDICES[1] or the entry behind the array (defined as 0: the diffuse sphere
+# is then sampled as if it were a light); the _fog scene runs the same choice in volumeLightSample (base.cl:202-207)
+def _twolights(medium=None, st=None):
+    doc = cornell({"color": WHITE, "type": 1}, medium=medium, st=st,
+                  extra_spheres=[])
+    doc["scene"]["spheres"] = [{"pos": [-1.1, 0.45, 0.7], "radius": 0.45, "material": {"color": [0.7, 0.7, 0.9], "type": 1}},
+                               {"pos": [0.6, 3.0, 0.0], "radius": 0.4, "material": {"color": [6.0, 5.0, 4.0], "type": 0}}]
+    doc["scene"]["quads"] = [quad([-1.2, 3.95, 0.6], [-1.0, 0.0, 0.0], [0.0, 0.0, 1.0], [3.0, 6.0, 9.0])] + box_quads()
+    doc["scene"]["quads"][0]["material"]["type"] = 0
+    return doc
+
+
+SCENES["cornell_twolights"] = _twolights(st=settings(16, 6, 16, 16, 16))
+SCENES["cornell_twolights_fog"] = _twolights(medium={"density": 0.25, "sigmaA": 0.05, "sigmaS": 1.0}, st=settings(12, 4, 16, 32, 64))
+
 if __name__ == "__main__":
     for name, doc in SCENES.items():
         with open(os.path.join(HERE, name + ".json"), "w") as f:

@@ -53,11 +53,23 @@ VARIANTS = {
     "cornell_edge": ("cornell_edge.json", 0, True),             # leaf-root BVH, pinhole camera, low bounce caps, TIR, mirror, skewed normals
     "cornell_absfog": ("cornell_absfog.json", 0, False),        # absorption-only medium
     "cornell_fogcap": ("cornell_fogcap.json", 1, True),         # dense HG medium running into MAX_SCATTERING_EVENTS
+    # PICK_RANDOM_LIGHT (kernels/integrators/base.cl:9 switched on in the reference build; prt_config::pick_random_light)
+    "cornell_twolights": ("cornell_twolights.json", 0, True),         # sphere + quad light behind a non-emitting mesh 0 (the entry past LIGHT_INDICES)
+    "cornell_twolights_fog": ("cornell_twolights_fog.json", 1, False),  # the same choice in volumeLightSample
 }
 # debug views of kernels/main.cl:6-15 (prt_config::view_option): fixture -> (base variant, view_option)
 VIEW_VARIANTS = {"cornell_mixed_viewnormal": ("cornell_mixed", 1), "cornell_media_hg_viewbvh": ("cornell_media_hg", 16)}
 PINHOLE_VARIANTS = {"cornell_edge"}                             # apertureRadius 0: camera.cl:44-56 takes the pinhole branch
+PICK_VARIANTS = {"cornell_twolights", "cornell_twolights_fog"}  # built / run with PICK_RANDOM_LIGHT (prt_config::pick_random_light)
 ALPHA_VARIANTS = {"cornell_quadlight"}                          # built / run with ALPHA_TESTING (the reference's -alpha flag)
+
+
+def variant_config(scene, variant):
+    """the prt_config of a variant: what the reference's loader derives from the scene file, plus the switches that are command-line
+    flags (-alpha) or source edits (PICK_RANDOM_LIGHT) in the reference"""
+    cfg = scene.config(alpha_testing=variant in ALPHA_VARIANTS)
+    cfg.pick_random_light = 1 if variant in PICK_VARIANTS else 0
+    return cfg
 
 
 def variant_camera(prt, variant, W, H):

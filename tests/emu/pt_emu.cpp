@@ -168,7 +168,7 @@ extern "C" int emu_render(const prt_config* cfg, const prt_scene_desc* desc, con
     }
     DevScene sc = ps.sc;
     sc.pairs = ps.pairs.data(); sc.tri_geom = ps.tg.data(); sc.tri_nrm = ps.tn.data();
-    sc.spheres = ps.spheres.data(); sc.quads = ps.quads.data(); sc.sdfs = ps.sdfs.data(); sc.mats = ps.mats.data();
+    sc.spheres = ps.spheres.data(); sc.quads = ps.quads.data(); sc.sdfs = ps.sdfs.data(); sc.mats = ps.mats.data(); sc.light_tab = ps.light_tab.data();
     static const float black[3] = {0.f, 0.f, 0.f};
     sc.env = env_rgb ? env_rgb : black; sc.env_w = env_rgb ? env_w : 1; sc.env_h = env_rgb ? env_h : 1;
     DevCamera cam{};
@@ -189,7 +189,10 @@ extern "C" int emu_render(const prt_config* cfg, const prt_scene_desc* desc, con
     for (int ty = 0; ty < tiles_y; ++ty)
         for (int tx = 0; tx < tiles_x; ++tx) {
             // the variant launch_render (pt_kernels.hip) picks
-            if (sc.view) {
+            if (sc.pick_random_light) {
+                if (!sc.has_medium) run_tile<PT_MATS_PICK, false>(sc, cam, fa, tx, ty, state, out_rgba, sched_seed, stack_mem, ahead);
+                else run_tile<PT_MATS_PICK, true>(sc, cam, fa, tx, ty, state, out_rgba, sched_seed, stack_mem, ahead);
+            } else if (sc.view) {
                 constexpr unsigned V = PT_MATS_VIEW, VS = PT_MATS_VIEW | PT_MATS_SDF;
                 if (sc.n_sdfs) {
                     if (!sc.has_medium) run_tile<VS, false>(sc, cam, fa, tx, ty, state, out_rgba, sched_seed, stack_mem, ahead);

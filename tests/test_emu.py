@@ -10,7 +10,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ALPHA_VARIANTS, GOLDEN, ROOT, VARIANTS, VIEW_VARIANTS, variant_camera
+from conftest import ALPHA_VARIANTS, variant_config, GOLDEN, ROOT, VARIANTS, VIEW_VARIANTS, variant_camera
 
 sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
 
@@ -25,7 +25,7 @@ def emu():
 def _scene(prt, variant, W, H):
     scene_json, phase, use_env = VARIANTS[variant]
     scene = prt.HostScene(scene_json)
-    cfg = scene.config(alpha_testing=variant in ALPHA_VARIANTS)
+    cfg = variant_config(scene, variant)
     cfg.phase_function = phase
     return scene, cfg, variant_camera(prt, variant, W, H), (prt.make_sky(64, 32) if use_env else None)
 

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import ALPHA_VARIANTS, GOLDEN, PKG_NAME, VARIANTS, VIEW_VARIANTS, variant_camera
+from conftest import ALPHA_VARIANTS, variant_config, GOLDEN, PKG_NAME, VARIANTS, VIEW_VARIANTS, variant_camera
 
 pytestmark = pytest.mark.gpu
 
@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 def _setup(prt, variant, W, H, rows=None, row0=0):
     scene_json, phase, use_env = VARIANTS[variant]
     scene = prt.HostScene(scene_json)
-    cfg = scene.config(alpha_testing=variant in ALPHA_VARIANTS)
+    cfg = variant_config(scene, variant)
     cfg.phase_function = phase
     cam = variant_camera(prt, variant, W, H)
     env = prt.make_sky(64, 32) if use_env else None

@@ -8,7 +8,7 @@ import struct
 import numpy as np
 import pytest
 
-from conftest import ALPHA_VARIANTS, GOLDEN, ROOT, VARIANTS
+from conftest import ALPHA_VARIANTS, variant_config, GOLDEN, ROOT, VARIANTS
 
 
 def read_blob(path):
@@ -40,7 +40,7 @@ def test_scene_loader_matches_reference_loader(prt, variant):
     assert np.array_equal(mine[:, MESH_MASK], ref[:, MESH_MASK])
     assert C.string_at(d.obj_material, 56) == b["objmat"][:56]
     ints = struct.unpack("<16i", b["ints"])
-    cfg = scene.config(alpha_testing=variant in ALPHA_VARIANTS)
+    cfg = variant_config(scene, variant)
     assert cfg.alpha_testing == ints[15]
     assert (cfg.max_bounces, cfg.max_diff_bounces, cfg.max_spec_bounces, cfg.max_trans_bounces, cfg.max_scattering_events,
             cfg.marching_steps, cfg.shadow_marching_steps) == ints[:7]

@@ -6,13 +6,13 @@ import os
 import numpy as np
 import pytest
 
-from conftest import ALPHA_VARIANTS, GOLDEN, VARIANTS, VIEW_VARIANTS, variant_camera
+from conftest import ALPHA_VARIANTS, variant_config, GOLDEN, VARIANTS, VIEW_VARIANTS, variant_camera
 
 
 def setup(prt, variant, W, H):
     scene_json, phase, use_env = VARIANTS[variant]
     scene = prt.HostScene(scene_json)
-    cfg = scene.config(alpha_testing=variant in ALPHA_VARIANTS)
+    cfg = variant_config(scene, variant)
     cfg.phase_function = phase
     return scene, cfg, variant_camera(prt, variant, W, H), (prt.make_sky(64, 32) if use_env else None)
 
