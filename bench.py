@@ -11,8 +11,8 @@ every pixel has finished its S-th path (the reference's "N spp" in its own work 
 SURVEY.md s8d).  Inputs (scene, BVH, camera, seed table) are resident in HBM before the timed
 region.  With N > 1 the frame is split into interleaved row blocks, one set per rank (pixels are
 independent; seeds use global pixel coordinates, so the union is bit-identical to the 1-GPU
-image of that frame), and ONE RCCL collective per step -- an all-gather of every rank's rows --
-puts the framebuffer together on rank 0, inside the timed region.  By default rank 0 then renders
+image of that frame), and ONE RCCL collective per step -- a gather of every rank's rows to rank 0 --
+puts the framebuffer together there, inside the timed region.  By default rank 0 then renders
 the whole frame alone (untimed) and the JSON line says whether the merged frame equals it bit for bit.
 
 Scaling.  Default "strong": the FIXED base frame (BASELINE config 2: 1920x1080, 1024 spp) split N
@@ -32,7 +32,13 @@ The JSON line also carries
                 all the launches of a step on the caller's stream, `avg_launch_ms` around each
                 launch on the internal stream it ran on -- two launches, covering interleaved sets
                 of tiles, are in flight at a time).  peak = 8 TB/s HBM3E.  `traffic` = measured HBM
-                bytes per launch from the rocprofv3 PMC passes under profiles/ (null if absent).
+                bytes per launch from the rocprofv3 PMC passes under profiles/ (null if absent), and
+                `measured_hbm_gbps` what that is per second of this run.  The path state lives in
+                registers for the 512 frames of a launch, so the measured traffic is ~2 % of the
+                algorithmic bytes: HBM is the bound SURVEY s8d prescribes for the accounting, not what
+                binds.  What does is in `valu`: vector instructions per wave-segment and lane occupancy
+                (PMC passes of the same workload, profiles/r03_pmc_render_kernel.json) and, from this
+                run's segment rate, the share of the chip's vector issue slots they take.
   cpu_baseline  oracle/pt_oracle.c (a scalar-per-pixel CPU port, multi-threaded over pixels) on a
                 bounded sample of the same workload, rank 0, N = 1 only.
 """
@@ -137,6 +143,7 @@ def run_workload(prt, par, torch, dist, np, a, world, rank, local_rank, scene_na
             verified = bool(np.array_equal(alone.view(np.uint32), merged[0].cpu().numpy().view(np.uint32)))
         dist.barrier()
 
+    variant = r.kernel_variant()
     counts = r.counts(spp)
     seg = torch.tensor([float(counts.segments), float(counts.samples)], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -148,7 +155,7 @@ def run_workload(prt, par, torch, dist, np, a, world, rank, local_rank, scene_na
     return {"W": W, "H": H, "spp": spp, "dt": dt, "msamples": W * H * spp * steps_ / dt / 1e6, "ms_per_step": dt / steps_ * 1e3,
             "total_segments": float(seg[0]), "total_samples": float(seg[1]), "own_segments": own_segments, "verified": verified,
             "kernel_ms": m["kernel_ms"], "kernel_sum_ms": m["kernel_sum_ms"], "launches": m["launches"], "concurrent": m["concurrent"],
-            "max_bounces": cfg.max_bounces}
+            "max_bounces": cfg.max_bounces, "variant": variant}
 
 
 def main():
@@ -224,7 +231,7 @@ def main():
         # rank-0 kernel: its own segments per step over its own kernel time
         achieved = ALGO_BYTES_PER_SEGMENT * own_segments * steps / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         traffic = None
-        for tname in ("r02_traffic.json", "r01_traffic.json"):
+        for tname in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if traffic is None and os.path.exists(tpath):
                 try:
@@ -233,6 +240,26 @@ def main():
                         traffic = tj.get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
+        avg_launch_ms = kernel_sum_ms / max(launches, 1)
+        gseg = own_segments * steps / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        valu = None
+        ppath = os.path.join(ROOT, "profiles", "r03_pmc_render_kernel.json")
+        if world == 1 and os.path.exists(ppath):
+            try:
+                pj = json.load(open(ppath))
+                if pj.get("workload_key") == "%dx%d_%s" % (a.width, a.height, a.scene):
+                    d = pj["derived"]
+                    vws = d["valu_per_wave_segment"]
+                    # 256 CUs x 4 SIMDs, one wave64 vector instruction per 2 cycles per SIMD at 2.4 GHz (MI355X_MICROARCH.md: wave scheduling)
+                    issue_peak = 1024 * 2.4e9 / 2.0
+                    valu = {"valu_per_wave_segment": round(vws, 1), "salu_per_wave_segment": round(d["salu_per_wave_segment"], 1),
+                            "lane_occupancy": round(d["lane_occupancy = SQ_THREAD_CYCLES_VALU/(64*SQ_ACTIVE_INST_VALU)"], 4),
+                            "wait_fraction": round(d["wait_fraction = SQ_WAIT_ANY/SQ_WAVE_CYCLES"], 4),
+                            "issue_frac": round(vws * (gseg * 1e9 / 64.0) / issue_peak, 4),
+                            "source": "profiles/r03_pmc_render_kernel.json (rocprofv3 --pmc passes of this workload at %s spp); issue_frac = "
+                                      "valu_per_wave_segment x this run's wave-segments/s / (1024 SIMDs x 2.4 GHz / 2)" % pj.get("spp", "?")}
+            except Exception:
+                valu = None
         out = {
             "metric": "Msamples/s (width x height x spp / s) at %dx%d" % (a.width, a.height),
             "value": round(res["msamples"], 3),
@@ -251,17 +278,20 @@ def main():
                        "mean_path_length": round(total_segments / max(total_samples, 1.0), 4),
                        "segments_per_step": total_segments,
                        "base_frame": "%dx%d" % (a.width, a.height),
-                       "parallelism": "single GPU" if world == 1 else "%s scaling: %dx%d frame in interleaved 16-row blocks over %d ranks + 1 RCCL all-gather of the rows per step" % (a.scaling, W, H, world)},
+                       "parallelism": "single GPU" if world == 1 else "%s scaling: %dx%d frame in interleaved 16-row blocks over %d ranks + 1 RCCL gather of the rows to rank 0 per step" % (a.scaling, W, H, world)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                         "kernel": "render_kernel", "algorithmic_bytes_per_segment": ALGO_BYTES_PER_SEGMENT,
-                         "launches": launches, "avg_launch_ms": round(kernel_sum_ms / max(launches, 1), 4),
+                         "measured_hbm_gbps": (round(traffic / (avg_launch_ms * 1e-3) * concurrent / 1e9, 2) if traffic and avg_launch_ms > 0 else None),
+                         "binds": "vector issue at about a third of the lanes + memory latency of the BVH walk, not HBM (see valu)",
+                         "valu": valu,
+                         "kernel": res["variant"], "algorithmic_bytes_per_segment": ALGO_BYTES_PER_SEGMENT,
+                         "launches": launches, "avg_launch_ms": round(avg_launch_ms, 4),
                          "concurrent_launches": concurrent, "kernel_wall_ms": round(kernel_ms, 3),
                          "note": "libprt keeps %d launches of render_kernel in flight (interleaved sets of tiles on internal streams): "
                                  "`achieved` = algorithmic bytes of all launches / wall time of the GPU work (HIP events around it); "
                                  "`avg_launch_ms` = mean duration of one launch (HIP events around each, = the profiler's average), "
                                  "launches x avg_launch_ms ~ %d x kernel_wall_ms" % (concurrent, concurrent),
-                         "gsegments_per_s": round(own_segments * steps / (kernel_ms * 1e-3) / 1e9, 4) if kernel_ms > 0 else 0.0},
+                         "gsegments_per_s": round(gseg, 4)},
         }
         if res["verified"] is not None:
             out["config"]["merged_frame_equals_single_gpu_render"] = res["verified"]

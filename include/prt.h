@@ -84,6 +84,14 @@ typedef struct prt_config {
                                       * probability 1 / (LIGHT_COUNT + 1).  That entry is defined here as 0 (mesh 0 is sampled as if it were
                                       * a light), which is what the reference build of the fixtures reads there (the array is declared one
                                       * element longer in the temporary text: zero-initialised).  Needs light_count < PRT_MAX_LIGHTS. */
+    uint32_t env_importance_sampling;/* NOT in the reference (it only looks the map up where a ray escapes, pathtracing.cl:72): 1 = at every
+                                      * vertex that samples the light (handleSurface, base.cl:168-172) the light-sample strategy is a coin flip
+                                      * between LIGHT_INDICES[0] and the ENVIRONMENT MAP, sampled in proportion to its luminance x sin(theta)
+                                      * and combined with the BSDF sample by the power heuristic; a BSDF-sampled ray that escapes adds the map
+                                      * with the complementary weight and ends its path in that segment.  The expectation of every pixel is
+                                      * the one of the default mode (a GPU test checks the converged pictures against each other); the random
+                                      * number sequence is not, so this mode has no bit-exact counterpart.  Surfaces only: refused together
+                                      * with a global medium, SDF primitives, a debug view or pick_random_light. */
 } prt_config;
 
 /* Host buffers of one scene, in the reference's layouts (src/main.cpp:93-122,401-418). */

@@ -46,7 +46,7 @@ class Config(C.Structure):
                 ("has_global_medium", C.c_int32), ("fog_density", C.c_float), ("fog_sigma_a", C.c_float),
                 ("fog_sigma_s", C.c_float), ("fog_sigma_t", C.c_float), ("fog_abs_only", C.c_int32),
                 ("alpha_testing", C.c_int32), ("phase_function", C.c_int32), ("phase_g", C.c_float),
-                ("view_option", C.c_uint32), ("pick_random_light", C.c_uint32)]
+                ("view_option", C.c_uint32), ("pick_random_light", C.c_uint32), ("env_importance_sampling", C.c_uint32)]
 
 
 class SceneDesc(C.Structure):

@@ -20,7 +20,7 @@ COMMON = ["-std=c++17", "-O3", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "
 HOST_SOURCES = ["host/scene.cpp", "host/camera.cpp", "host/model_loader.cpp", "host/bvh.cpp", "host/hdr_loader.cpp", "host/host_capi.cpp"]
 # the render kernel is instantiated per compile-time material set in a file of its own (pt_inst_*.hip): they compile in parallel
 HIP_SOURCES = ["hip/prt_api.cpp", "hip/pt_pack.cpp", "hip/pt_kernels.hip"] + \
-    ["hip/pt_inst_%s.hip" % k for k in ("light_diff", "coat", "rough_cond", "rough_diel", "generic", "sdf", "view", "view_sdf", "pick")]
+    ["hip/pt_inst_%s.hip" % k for k in ("light_diff", "coat", "rough_cond", "rough_diel", "generic", "sdf", "view", "view_sdf", "pick", "envis")]
 
 
 def newer(src, obj, deps):

@@ -32,7 +32,7 @@ struct prt_ctx {
     // scene
     DevScene sc{};
     void* d_pairs = nullptr; void* d_tri_geom = nullptr; void* d_tri_nrm = nullptr;
-    void* d_spheres = nullptr; void* d_quads = nullptr; void* d_sdfs = nullptr; void* d_mats = nullptr; void* d_light_tab = nullptr; void* d_env = nullptr;
+    void* d_spheres = nullptr; void* d_quads = nullptr; void* d_sdfs = nullptr; void* d_mats = nullptr; void* d_light_tab = nullptr; void* d_env = nullptr; void* d_env_rows = nullptr; void* d_env_cols = nullptr;
     bool have_scene = false, have_cam = false, have_size = false;
     bool state_undefined = false;   // a render call failed half-way (prt_render_spp's abort path): pixels may be ahead of the launch windows
                                     // (run-ahead leads in the state) -- the state is unusable until prt_reset / prt_write_state
@@ -171,7 +171,7 @@ extern "C" void prt_destroy(prt_ctx* c) {
     if (c->h_unfinished) (void)hipHostFree(c->h_unfinished);
     free_frame(c);
     free_scene(c);
-    free_dev(c->d_env);
+    free_dev(c->d_env); free_dev(c->d_env_rows); free_dev(c->d_env_cols);
     void* p = c->d_seeds; free_dev(p);
     p = c->d_counters; free_dev(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -201,8 +201,9 @@ extern "C" int prt_upload_scene(prt_ctx* c, const prt_scene_desc* s) {
     // from here on the old buffers are being replaced: the context has no scene until every upload has succeeded
     c->have_scene = false;
     const float* env = c->sc.env; const int env_w = c->sc.env_w, env_h = c->sc.env_h;    // the environment map survives scene uploads
+    const float* env_rows = c->sc.env_cdf_rows; const float* env_cols = c->sc.env_cdf_cols;
     c->sc = DevScene{};
-    c->sc.env = env; c->sc.env_w = env_w; c->sc.env_h = env_h;
+    c->sc.env = env; c->sc.env_w = env_w; c->sc.env_h = env_h; c->sc.env_cdf_rows = env_rows; c->sc.env_cdf_cols = env_cols;
     if ((rc = upload(c, c->d_pairs, ps.pairs)) || (rc = upload(c, c->d_tri_geom, ps.tg)) || (rc = upload(c, c->d_tri_nrm, ps.tn)) ||
         (rc = upload(c, c->d_spheres, ps.spheres)) || (rc = upload(c, c->d_quads, ps.quads)) || (rc = upload(c, c->d_sdfs, ps.sdfs)) ||
         (rc = upload(c, c->d_mats, ps.mats)) || (rc = upload(c, c->d_light_tab, ps.light_tab)))
@@ -216,7 +217,7 @@ extern "C" int prt_upload_scene(prt_ctx* c, const prt_scene_desc* s) {
     sc.sdfs = static_cast<const DevSdf*>(c->d_sdfs);
     sc.mats = static_cast<const DevMaterial*>(c->d_mats);
     sc.light_tab = static_cast<const uint32_t*>(c->d_light_tab);
-    sc.env = env; sc.env_w = env_w; sc.env_h = env_h;
+    sc.env = env; sc.env_w = env_w; sc.env_h = env_h; sc.env_cdf_rows = env_rows; sc.env_cdf_cols = env_cols;
     c->sc = sc;
     if (!c->sc.env) {
         const float black[3] = {0.f, 0.f, 0.f};
@@ -246,6 +247,17 @@ extern "C" int prt_upload_envmap(prt_ctx* c, const float* rgb, int w, int h) {
     HIPCHK(c, hipMemcpy(c->d_env, rgb, bytes, hipMemcpyHostToDevice));
     c->sc.env = static_cast<const float*>(c->d_env);
     c->sc.env_w = w; c->sc.env_h = h;
+    free_dev(c->d_env_rows); free_dev(c->d_env_cols);
+    c->sc.env_cdf_rows = c->sc.env_cdf_cols = nullptr;
+    if (c->cfg.env_importance_sampling) {                       // the map's sampling density (pt_kernels.hip build_env_cdf)
+        std::vector<float> rows, cols;
+        build_env_cdf(rgb, w, h, rows, cols);
+        int rc = upload(c, c->d_env_rows, rows);
+        if (!rc) rc = upload(c, c->d_env_cols, cols);
+        if (rc) return rc;
+        c->sc.env_cdf_rows = static_cast<const float*>(c->d_env_rows);
+        c->sc.env_cdf_cols = static_cast<const float*>(c->d_env_cols);
+    }
     return PRT_OK;
 }
 

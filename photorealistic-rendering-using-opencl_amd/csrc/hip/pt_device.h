@@ -1027,7 +1027,9 @@ PT_DEV float coat_pdf(const Event& e, const Mat& mat) {
 #define PT_MATS_VIEW 0x40000000u
 // PT_MATS_PICK bit: PICK_RANDOM_LIGHT of kernels/integrators/base.cl:9 (prt_config::pick_random_light)
 #define PT_MATS_PICK 0x20000000u
-#define PT_MATS_FLAGS (PT_MATS_SDF | PT_MATS_VIEW | PT_MATS_PICK)
+// PT_MATS_ENVIS bit: prt_config::env_importance_sampling (not in the reference)
+#define PT_MATS_ENVIS 0x10000000u
+#define PT_MATS_FLAGS (PT_MATS_SDF | PT_MATS_VIEW | PT_MATS_PICK | PT_MATS_ENVIS)
 template <unsigned MATS>
 PT_DEV unsigned active_mats(const DevScene& sc) { return (MATS & ~PT_MATS_FLAGS) ? (MATS & ~PT_MATS_FLAGS) : sc.active_mats; }
 
@@ -1168,6 +1170,53 @@ PT_DEV f3 env_lookup(const DevScene& sc, f3 dir) {
     return t00 * ((1.f - a) * (1.f - b)) + t10 * (a * (1.f - b)) + t01 * ((1.f - a) * b) + t11 * (a * b);
 }
 
+// ---- environment-map importance sampling (prt_config::env_importance_sampling; not in the reference) -----------------------------
+// The density lives on the unit square of envMapEquirect's (u, v) (utils.cl:46): piecewise constant per texel, proportional to
+// what prt_upload_envmap built from the texel's neighbourhood maximum of the luminance x sin(theta) (+ a uniform floor, so that it
+// is positive wherever the bilinear lookup can be).  pdf over directions = p(u, v) / (2 pi^2 sin(theta)).
+struct EnvSample { f3 d; float pdf; };
+PT_DEV unsigned cdf_find(const float* __restrict__ cdf, unsigned n, float xi) {        // largest k < n with cdf[k] <= xi (cdf[0] = 0, cdf[n] = 1)
+    unsigned lo = 0u, hi = n;
+    while (hi - lo > 1u) { const unsigned mid = (lo + hi) >> 1; if (cdf[mid] <= xi) lo = mid; else hi = mid; }
+    return lo;
+}
+PT_DEV float env_texel_pdf(const DevScene& sc, unsigned i, unsigned j, float v) {     // density over directions at texel (i, j), polar coordinate v in [0, 1]
+    const float* cols = sc.env_cdf_cols + (size_t)j * (unsigned)(sc.env_w + 1);
+    const float prow = sc.env_cdf_rows[j + 1u] - sc.env_cdf_rows[j], pcol = cols[i + 1u] - cols[i];
+    const float sin_theta = prt_sin(v * PT_PI);
+    if (!(sin_theta > 0.0f)) return 0.0f;
+    return prow * pcol * (float)sc.env_w * (float)sc.env_h / (2.0f * PT_PI * PT_PI * sin_theta);
+}
+PT_DEV EnvSample env_sample(const DevScene& sc, float xi0, float xi1) {
+    const unsigned j = cdf_find(sc.env_cdf_rows, (unsigned)sc.env_h, xi0);
+    const float r0 = sc.env_cdf_rows[j], r1 = sc.env_cdf_rows[j + 1u];
+    const float* cols = sc.env_cdf_cols + (size_t)j * (unsigned)(sc.env_w + 1);
+    const unsigned i = cdf_find(cols, (unsigned)sc.env_w, xi1);
+    const float c0 = cols[i], c1 = cols[i + 1u];
+    const float fv = r1 > r0 ? (xi0 - r0) / (r1 - r0) : 0.5f, fu = c1 > c0 ? (xi1 - c0) / (c1 - c0) : 0.5f;
+    const float u = ((float)i + fu) / (float)sc.env_w, v = ((float)j + fv) / (float)sc.env_h;
+    const float phi = (u - 0.5f) * PT_TWO_PI, theta = v * PT_PI;
+    const float st = prt_sin(theta);
+    EnvSample es;
+    es.d = F3(st * prt_cos(phi), prt_cos(theta), st * prt_sin(phi));                   // the inverse of envMapEquirect
+    es.pdf = env_texel_pdf(sc, i, j, v);
+    return es;
+}
+PT_DEV float env_pdf(const DevScene& sc, f3 dir) {
+    const float cx = (prt_atan2(dir.z, dir.x) * PT_INV_TWO_PI) + 0.5f, cy = prt_acos(dir.y) * PT_INV_PI;
+    if (!(cx == cx) || !(cy == cy)) return 0.0f;
+    int i = (int)(cx * (float)sc.env_w), j = (int)(cy * (float)sc.env_h);
+    i = i < 0 ? 0 : (i >= sc.env_w ? sc.env_w - 1 : i);
+    j = j < 0 ? 0 : (j >= sc.env_h ? sc.env_h - 1 : j);
+    return env_texel_pdf(sc, (unsigned)i, (unsigned)j, cy);
+}
+// the density a BSDF sample of direction e.wo was drawn with (LambertBSDF_pdf as the reference compiles it is 0: SURVEY s9-Q7)
+template <unsigned MATS>
+PT_DEV float bsdf_pdf_sampling(const DevScene& sc, const Event& e, const Mat& mat) {
+    if (mat.t & active_mats<MATS>(sc) & PRT_MAT_DIFF) return (e.wi.z <= 0.0f || e.wo.z <= 0.0f) ? 0.0f : prt_fabs(e.wo.z) * PT_INV_PI;
+    return bsdf_pdf<MATS>(sc, e, mat);
+}
+
 PT_DEV float power_heuristic(float pdf0, float pdf1) { return (pdf0 * pdf0) / (pdf0 * pdf0 + pdf1 * pdf1); }
 
 // ---- per-pixel state in registers: the lane machine ------------------------------------------------------------
@@ -1261,6 +1310,7 @@ struct Lane {
     unsigned fresh : 1;      // the walk asked for has not started
     unsigned w2 : 1;         // the closest-hit walk in flight is the probe (W2), else the path ray (W1)
     unsigned occluded : 1;
+    unsigned sh_vertex : 1;  // PT_MATS_ENVIS: the shadow ray starts at the vertex (= origin of the probe), not where the probe ended
 };
 
 // position of the hit in L.h: intersect_scene's `ray.pos = ray.origin + ray.dir * t` (same operations, same bits) on the ray that was walked
@@ -1275,6 +1325,7 @@ PT_DEV void lane_init(Lane& L) {
     L.w.node = 0u; L.w.sp = 0u; L.w.pend_count = 0u; L.w.pend_first = 0u; L.w.t = 0.0f; L.w.u = L.w.v = 0.0f; L.w.slot = 0u; L.w.found = false; L.w.done = true; L.w.last = false;
     L.f = 0u; L.stage = ST_READY;
     L.begun = L.fresh = L.w2 = L.occluded = false;
+    L.sh_vertex = false;
 }
 
 // may this lane start (or go on with) a segment?  The "N spp" rule freezes a pixel at a segment boundary.
@@ -1486,7 +1537,9 @@ PT_DEV void lane_back(const DevScene& sc, Lane& L) {
     const f3 hit_pos = lane_hit_pos(L);
     L.a = splat(0.0f);                                                   // (from here on the words of the finished walk's (t, u, v) are `a`)
     f3 sh_o = hit_pos;
+    if (MATS & PT_MATS_ENVIS) L.sh_vertex = false;
     if (L.kind == K_SURFACE_MIS) {
+        constexpr bool ENVIS = (MATS & PT_MATS_ENVIS) != 0;
         const Mat mat = load_mat((L.mesh_id + 1) ? &sc.mats[L.mesh_id + 1] : &sc.mats[sc.n_meshes + 1]);
         if (L.w2_ran && L.h.didHit) {                                    // the probe ray, base.cl:58-75
             const int mid = L.h.mesh_id;
@@ -1496,23 +1549,50 @@ PT_DEV void lane_back(const DevScene& sc, Lane& L) {
                 L.a = lm.color * L.weight * power_heuristic(L.pdf, direct_pdf_mesh(sc, mid, L.dir, hit_pos));
                 if (MEDIUM) L.a = L.a * vexp(splat(sc.fog_sigma_t) * (-1.0f * L.t));
             }
+        } else if (ENVIS && L.w2_ran) {
+            // the BSDF-sampled ray escapes: the map along it, weighted against the map's own sampling strategy (a mirror direction
+            // cannot be produced by it), and the path ends here instead of in a segment of its own
+            const float w = (L.sampledLobe & PRT_LOBE_SPECULAR) ? 1.0f : power_heuristic(L.pdf, 0.5f * env_pdf(sc, L.dir));
+            L.a = env_lookup(sc, L.dir) * L.weight * w;
+            L.terminate = true;
         }
         // lightSample, base.cl:79-134 (from ray.pos = the probe ray's hit point: SURVEY s9-Q4)
-        LightSample rec;
-        unsigned lmesh;
-        if (sample_light(sc, (MATS & PT_MATS_PICK) != 0, hit_pos, rec, L.rng, lmesh)) {
-            Event e;
-            e.frame = make_frame(L.n_shade);
-            e.wi = L.wi; e.weight = L.weight; e.pdf = L.pdf; e.sampledLobe = L.sampledLobe;
-            e.wo = to_local(e.frame, rec.d);
-            const f3 fr = bsdf_eval2<MATS>(sc, e, mat);
-            if (!(dot(fr, fr) == 0.0f)) {
-                L.sh = true; L.sh_d = rec.d; L.sh_tmax = rec.dist;
-                const Mat lm = load_mat(&sc.mats[lmesh + 1]);
-                f3 contribution = lm.color * fr;
-                if (MEDIUM) contribution = contribution * vexp(splat(sc.fog_sigma_t) * (-1.0f * rec.dist));
-                contribution = contribution * power_heuristic(rec.pdf, bsdf_pdf<MATS>(sc, e, mat));
-                L.vis = contribution / rec.pdf;
+        if (ENVIS && next1D(L.rng) < 0.5f) {                             // the light-sample strategy of this vertex is the environment map
+            const float xi0 = next1D(L.rng), xi1 = next1D(L.rng);
+            const EnvSample es = env_sample(sc, xi0, xi1);
+            if (es.pdf > 0.0f) {
+                Event e;
+                e.frame = make_frame(L.n_shade);
+                e.wi = L.wi; e.weight = L.weight; e.pdf = L.pdf; e.sampledLobe = L.sampledLobe;
+                e.wo = to_local(e.frame, es.d);
+                const f3 fr = bsdf_eval2<MATS>(sc, e, mat);
+                if (!(dot(fr, fr) == 0.0f)) {
+                    // (the reference samples its light from where the PROBE ended; the map is sampled from the vertex, which
+                    // is what its BSDF-sampled counterpart sees: the probe's origin, or -- no probe -- the hit point itself)
+                    if (L.w2_ran) { sh_o = L.origin; L.sh_vertex = true; }
+                    L.sh = true; L.sh_d = es.d; L.sh_tmax = PT_INF;
+                    const float pe = 0.5f * es.pdf;
+                    L.vis = env_lookup(sc, es.d) * fr * (power_heuristic(pe, bsdf_pdf_sampling<MATS>(sc, e, mat)) / pe);
+                }
+            }
+        } else {
+            LightSample rec;
+            unsigned lmesh;
+            if (sample_light(sc, (MATS & PT_MATS_PICK) != 0, hit_pos, rec, L.rng, lmesh)) {
+                Event e;
+                e.frame = make_frame(L.n_shade);
+                e.wi = L.wi; e.weight = L.weight; e.pdf = L.pdf; e.sampledLobe = L.sampledLobe;
+                e.wo = to_local(e.frame, rec.d);
+                const f3 fr = bsdf_eval2<MATS>(sc, e, mat);
+                if (!(dot(fr, fr) == 0.0f)) {
+                    L.sh = true; L.sh_d = rec.d; L.sh_tmax = rec.dist;
+                    const Mat lm = load_mat(&sc.mats[lmesh + 1]);
+                    f3 contribution = lm.color * fr;
+                    if (MEDIUM) contribution = contribution * vexp(splat(sc.fog_sigma_t) * (-1.0f * rec.dist));
+                    contribution = contribution * power_heuristic(rec.pdf, bsdf_pdf<MATS>(sc, e, mat));
+                    L.vis = contribution / rec.pdf;
+                    if (ENVIS) L.vis = L.vis * 2.0f;                     // (the light was the coin's other side: probability 1 / 2)
+                }
             }
         }
     } else if (MEDIUM && L.kind == K_SCATTER) {
@@ -1534,10 +1614,10 @@ PT_DEV void lane_back(const DevScene& sc, Lane& L) {
     else { L.stage = ST_FINISH; L.occluded = false; }
 }
 
-template <bool MEDIUM>
+template <bool MEDIUM, bool ENVIS = false>
 PT_DEV Ray lane_shadow_ray(const Lane& L) {
     Ray r;
-    r.origin = (MEDIUM && L.kind == K_SCATTER) ? L.origin : lane_hit_pos(L);
+    r.origin = ((MEDIUM && L.kind == K_SCATTER) || (ENVIS && L.sh_vertex)) ? L.origin : lane_hit_pos(L);
     r.dir = L.sh_d; r.normal = splat(0.0f); r.pos = splat(0.0f); r.t = L.sh_tmax; r.backside = false; r.time = 0.0f;
     return r;
 }

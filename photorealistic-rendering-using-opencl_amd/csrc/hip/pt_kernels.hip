@@ -21,6 +21,7 @@
 #include "pt_inst_view.hip"
 #include "pt_inst_view_sdf.hip"
 #include "pt_inst_pick.hip"
+#include "pt_inst_envis.hip"
 #endif
 #elif defined(PT_PHASE_CLOCKS) || defined(PT_DEV_ONE_VARIANT)
 #error "PT_PHASE_CLOCKS / PT_DEV_ONE_VARIANT builds are unity builds: add -DPT_UNITY"
@@ -226,6 +227,7 @@ RenderLaunch launch_render(const DevScene& sc, const DevCamera& cam, const DevSt
     if (sc.n_sdfs || medium || sc.view || am != (PRT_MAT_LIGHT | PRT_MAT_DIFF)) return RenderLaunch{};
     return launch_set_light_diff(false, sc, cam, S, fa, fb, stream, lo);
 #else
+    if (sc.env_is) return launch_set_envis(medium, sc, cam, S, fa, fb, stream, lo);              // (pack_scene refuses it with a medium, SDFs, views, the light pick)
     if (sc.pick_random_light) return launch_set_pick(medium, sc, cam, S, fa, fb, stream, lo);     // PICK_RANDOM_LIGHT: the generic set (pack_scene refuses it with SDFs / views)
     if (sc.view) return sc.n_sdfs ? launch_set_view_sdf(medium, sc, cam, S, fa, fb, stream, lo) : launch_set_view(medium, sc, cam, S, fa, fb, stream, lo);
     if (sc.n_sdfs) return launch_set_sdf(medium, sc, cam, S, fa, fb, stream, lo);      // H_SDF scenes: the generic set with the raymarcher

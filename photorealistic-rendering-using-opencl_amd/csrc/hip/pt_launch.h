@@ -32,6 +32,8 @@ PT_DECLARE_SET(launch_set_sdf);
 PT_DECLARE_SET(launch_set_view);
 PT_DECLARE_SET(launch_set_view_sdf);
 PT_DECLARE_SET(launch_set_pick);
+PT_DECLARE_SET(launch_set_envis);
+
 // workgroups (tiles) launch_render uses for a width x rows frame part
 unsigned render_tile_count(int width, int rows);
 #ifdef PT_PHASE_CLOCKS

@@ -83,6 +83,10 @@ struct DevScene {
     const DevMaterial* mats;        // [0] guard (zero), [1+i] mesh i, [1+n_meshes] OBJ material
     const float* env;               // RGB float
     int env_w, env_h;
+    // prt_config::env_importance_sampling (the PT_MATS_ENVIS kernel variants): the map's sampling density as cumulative sums --
+    // env_cdf_rows[j], j = 0 .. env_h: rows 0 .. j - 1; env_cdf_cols[j * (env_w + 1) + i]: texels 0 .. i - 1 of row j (each ends at 1)
+    const float* env_cdf_rows;
+    const float* env_cdf_cols;
     uint32_t n_spheres, n_quads, quad_mesh_base, n_meshes, n_sdfs;
     int marching_steps, shadow_marching_steps;
     unsigned stack_levels;          // LDS traversal-stack levels per lane (most entries any walk can hold, + 1)
@@ -95,6 +99,7 @@ struct DevScene {
     // and, at [light_count], of the entry behind it (0)
     const uint32_t* light_tab;
     uint32_t light_count, pick_random_light;
+    uint32_t env_is;                // prt_config::env_importance_sampling
     // prt_config
     uint32_t active_mats, geom_flags;
     int max_bounces, max_diff_bounces, max_spec_bounces, max_trans_bounces, max_scattering_events;

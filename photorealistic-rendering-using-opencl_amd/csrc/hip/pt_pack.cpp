@@ -19,6 +19,50 @@ static DevMaterial pack_material(const prt_material& m) {
     return d;
 }
 
+// Sampling density of an environment map for prt_config::env_importance_sampling: per texel the largest luminance of its 3 x 3
+// neighbourhood (the bilinear lookup of a direction inside the texel can reach that far; columns wrap, rows clamp) x sin(theta) of its
+// row, plus 5 % of the mean as a floor -- positive wherever the lookup can be.  Normalised cumulative sums in double precision.
+void build_env_cdf(const float* rgb, int w, int h, std::vector<float>& rows, std::vector<float>& cols) {
+    std::vector<double> f((size_t)w * h);
+    auto lum = [&](int i, int j) {
+        i = (i % w + w) % w; j = j < 0 ? 0 : (j >= h ? h - 1 : j);
+        const float* p = rgb + ((size_t)j * w + i) * 3;
+        const double l = 0.2126 * p[0] + 0.7152 * p[1] + 0.0722 * p[2];
+        return l > 0.0 && l < 1e30 ? l : 0.0;
+    };
+    double total = 0.0;
+    for (int j = 0; j < h; ++j) {
+        const double st = std::sin(3.14159265358979323846 * (j + 0.5) / h);
+        for (int i = 0; i < w; ++i) {
+            double m = 0.0;
+            for (int dj = -1; dj <= 1; ++dj) for (int di = -1; di <= 1; ++di) m = std::fmax(m, lum(i + di, j + dj));
+            f[(size_t)j * w + i] = m * st;
+            total += m * st;
+        }
+    }
+    const double floor_ = total > 0.0 ? 0.05 * total / ((double)w * h) : 1.0;
+    rows.assign((size_t)h + 1, 0.0f);
+    cols.assign((size_t)h * (w + 1), 0.0f);
+    std::vector<double> row_sum(h);
+    double all = 0.0;
+    for (int j = 0; j < h; ++j) {
+        const double st = std::sin(3.14159265358979323846 * (j + 0.5) / h);
+        double s = 0.0;
+        for (int i = 0; i < w; ++i) { f[(size_t)j * w + i] += floor_ * st / 0.6366197723675814; s += f[(size_t)j * w + i]; }   // (floor in proportion to the solid angle)
+        row_sum[j] = s; all += s;
+    }
+    double acc = 0.0;
+    for (int j = 0; j < h; ++j) {
+        rows[j] = (float)(acc / all);
+        acc += row_sum[j];
+        double c = 0.0;
+        float* cj = cols.data() + (size_t)j * (w + 1);
+        for (int i = 0; i < w; ++i) { cj[i] = (float)(c / row_sum[j]); c += f[(size_t)j * w + i]; }
+        cj[w] = 1.0f;
+    }
+    rows[h] = 1.0f;
+}
+
 int pack_scene(const prt_config& cfg, const prt_scene_desc* s, PackedScene& out, std::string& err) {
     auto fail = [&err](int, int code, const char* msg) { err = msg; return code; };
     const int c = 0;
@@ -202,6 +246,9 @@ int pack_scene(const prt_config& cfg, const prt_scene_desc* s, PackedScene& out,
         if (n_sdf || cfg.view_option != PRT_VIEW_RESULTS)
             return fail(c, PRT_ERR_UNSUPPORTED, "prt_upload_scene: pick_random_light is not built together with SDF primitives or a debug view");
     }
+    if (cfg.env_importance_sampling && (cfg.has_global_medium || n_sdf || cfg.view_option != PRT_VIEW_RESULTS || cfg.pick_random_light))
+        return fail(c, PRT_ERR_UNSUPPORTED, "prt_upload_scene: env_importance_sampling is built for surfaces only (no global medium, SDF primitives, debug view, pick_random_light)");
+    sc.env_is = cfg.env_importance_sampling ? 1u : 0u;
     if (cfg.light_count) {
         const uint32_t li = cfg.light_indices[0];
         if (li >= n_mesh) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: light index out of range");

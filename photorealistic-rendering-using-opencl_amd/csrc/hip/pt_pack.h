@@ -22,6 +22,9 @@ struct PackedScene {
     DevScene sc{};             // every scalar field; the pointers (and env) are filled in by whoever owns the memory
 };
 
+// prt_config::env_importance_sampling: the sampling density of an environment map as cumulative sums (DevScene::env_cdf_rows / _cols)
+void build_env_cdf(const float* rgb, int w, int h, std::vector<float>& rows, std::vector<float>& cols);
+
 // PRT_OK, or the prt error code with its message in `err`.  Nothing outside `out` is touched.
 int pack_scene(const prt_config& cfg, const prt_scene_desc* s, PackedScene& out, std::string& err);
 

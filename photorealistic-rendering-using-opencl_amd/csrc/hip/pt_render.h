@@ -156,7 +156,7 @@ __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene 
         PT_CLK(3);
         {                                                                                                 // D
             const bool walking = L.stage == ST_WALKS;
-            const Ray wr = lane_shadow_ray<MEDIUM>(L);
+            const Ray wr = lane_shadow_ray<MEDIUM, (MATS & PT_MATS_ENVIS) != 0>(L);
             const RayPre p = ray_pre(wr);
             if (walking && L.fresh) { walk_begin(sc, true, wr, wr.t, p, L.w, stk); L.fresh = false; }
             const bool go = walking && !L.w.done;

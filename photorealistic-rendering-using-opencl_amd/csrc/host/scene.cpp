@@ -237,6 +237,7 @@ prt_config host_scene::make_config(bool alpha_testing) const {
     c.phase_g = 0.6f;                             // kernels/phasefunctions/HenyeyGreenstein.cl:4
     c.view_option = PRT_VIEW_RESULTS;             // kernels/main.cl:15
     c.pick_random_light = 0;                      // kernels/integrators/base.cl:9
+    c.env_importance_sampling = 0;                // (not in the reference)
     return c;
 }
 

@@ -129,6 +129,14 @@ def _twolights(medium=None, st=None):
 SCENES["cornell_twolights"] = _twolights(st=settings(16, 6, 16, 16, 16))
 SCENES["cornell_twolights_fog"] = _twolights(medium={"density": 0.25, "sigmaA": 0.05, "sigmaS": 1.0}, st=settings(12, 4, 16, 32, 64))
 
+# an OPEN box (floor, back wall, one side wall) under the sky: the scene of the environment-map importance-sampling tests
+# (prt_config::env_importance_sampling; in the closed Cornell box the map is only ever seen by camera rays)
+SCENES["cornell_open"] = cornell({"color": WHITE, "type": 1}, st=settings(12, 6, 12, 12, 12),
+                                 extra_spheres=[{"pos": [1.1, 0.45, 0.6], "radius": 0.45, "material": {"color": [0.9, 0.8, 0.6], "type": 10, "dist": 2, "roughness": 0.3}},
+                                                {"pos": [-1.2, 0.4, 0.9], "radius": 0.4, "material": {"color": [0.95, 0.95, 0.95], "type": 4, "roughness": 0.15}}],
+                                 light={"pos": [0.0, 3.0, 0.0], "radius": 0.25, "material": {"color": [8.0, 8.0, 8.0], "type": 0}})
+SCENES["cornell_open"]["scene"]["quads"] = [box_quads()[k] for k in (0, 3, 5)]
+
 if __name__ == "__main__":
     for name, doc in SCENES.items():
         with open(os.path.join(HERE, name + ".json"), "w") as f:

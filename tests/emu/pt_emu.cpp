@@ -76,7 +76,7 @@ void run_tile(const DevScene& sc, const DevCamera& cam, const FrameArgs& fa, int
             Lane& l = L[lane];
             const bool walking = l.stage == walk_stage;
             if (walking) {
-                wr[lane] = any_hit ? lane_shadow_ray<MEDIUM>(l) : lane_closest_ray<MEDIUM>(l);
+                wr[lane] = any_hit ? lane_shadow_ray<MEDIUM, (MATS & PT_MATS_ENVIS) != 0>(l) : lane_closest_ray<MEDIUM>(l);
                 p[lane] = ray_pre(wr[lane]);
                 if (l.fresh) { walk_begin(sc, any_hit, wr[lane], any_hit ? wr[lane].t : PT_INF, p[lane], l.w, stk[lane]); l.fresh = false; }
             }
@@ -171,6 +171,11 @@ extern "C" int emu_render(const prt_config* cfg, const prt_scene_desc* desc, con
     sc.spheres = ps.spheres.data(); sc.quads = ps.quads.data(); sc.sdfs = ps.sdfs.data(); sc.mats = ps.mats.data(); sc.light_tab = ps.light_tab.data();
     static const float black[3] = {0.f, 0.f, 0.f};
     sc.env = env_rgb ? env_rgb : black; sc.env_w = env_rgb ? env_w : 1; sc.env_h = env_rgb ? env_h : 1;
+    std::vector<float> cdf_rows, cdf_cols;
+    if (cfg->env_importance_sampling) {
+        build_env_cdf(sc.env, sc.env_w, sc.env_h, cdf_rows, cdf_cols);
+        sc.env_cdf_rows = cdf_rows.data(); sc.env_cdf_cols = cdf_cols.data();
+    }
     DevCamera cam{};
     camera_basis(*camera, cam);
     FrameArgs fa{};
@@ -189,7 +194,9 @@ extern "C" int emu_render(const prt_config* cfg, const prt_scene_desc* desc, con
     for (int ty = 0; ty < tiles_y; ++ty)
         for (int tx = 0; tx < tiles_x; ++tx) {
             // the variant launch_render (pt_kernels.hip) picks
-            if (sc.pick_random_light) {
+            if (sc.env_is) {
+                run_tile<PT_MATS_ENVIS, false>(sc, cam, fa, tx, ty, state, out_rgba, sched_seed, stack_mem, ahead);
+            } else if (sc.pick_random_light) {
                 if (!sc.has_medium) run_tile<PT_MATS_PICK, false>(sc, cam, fa, tx, ty, state, out_rgba, sched_seed, stack_mem, ahead);
                 else run_tile<PT_MATS_PICK, true>(sc, cam, fa, tx, ty, state, out_rgba, sched_seed, stack_mem, ahead);
             } else if (sc.view) {

@@ -119,3 +119,31 @@ def test_ragged_frame_and_row_blocks_on_host(prt, oracle, emu, variant):
     bstate, bimg = emu.render(oracle.PATH_STATE_DTYPE, cfg, scene.desc, cam, W, H, seeds, env=env, sched_seed=8, blocks=blocks)
     rows = [r for r in range(H) if (r // blocks[0]) % blocks[1] == blocks[2]]
     assert oracle.images_equal(oimg[rows], bimg), "row blocks differ from the full frame"
+
+
+def _mean_and_error(img):
+    """per channel: mean over the finite pixels and its Monte-Carlo error from the spread of 4 x 4 block means"""
+    h, w = img.shape[0] // 4 * 4, img.shape[1] // 4 * 4
+    a = np.nan_to_num(img[:h, :w, :3].astype(np.float64), nan=0.0, posinf=0.0, neginf=0.0)
+    blocks = a.reshape(h // 4, 4, w // 4, 4, 3).mean(axis=(1, 3)).reshape(-1, 3)
+    return a.mean(axis=(0, 1)), blocks.std(axis=0, ddof=1) / np.sqrt(blocks.shape[0])
+
+
+def test_environment_importance_sampling_has_the_same_expectation_on_host(prt, oracle, emu):
+    """prt_config::env_importance_sampling (not in the reference): the light-sample strategy of a vertex is a coin flip between the light
+    and the environment map (sampled by luminance x sin theta, power heuristic against the BSDF sample).  The estimator changes, the
+    expectation must not: an open box under the sky, both modes, image means within the Monte-Carlo error of their difference"""
+    W, H, frames = 24, 16, 3072
+    scene = prt.HostScene("cornell_open.json")
+    cam = prt.default_camera(W, H)
+    env = prt.make_sky(64, 32)
+    seeds = prt.seed_pairs(frames)
+    out = {}
+    for mode in (0, 1):
+        cfg = scene.config()
+        cfg.env_importance_sampling = mode
+        _, img = emu.render(oracle.PATH_STATE_DTYPE, cfg, scene.desc, cam, W, H, seeds, env=env)
+        out[mode] = _mean_and_error(img)
+    (m0, e0), (m1, e1) = out[0], out[1]
+    z = (m1 - m0) / np.sqrt(e0 ** 2 + e1 ** 2)
+    assert (np.abs(z) < 4.5).all() and (np.abs(m1 / m0 - 1.0) < 0.05).all(), "means %s vs %s (z = %s)" % (m0, m1, z)

@@ -484,6 +484,75 @@ def test_compiled_material_sets_and_generic_dispatch_match_golden(prt, oracle, v
     assert "generic" in forced, forced
 
 
+def _mean_and_error(img):
+    """per channel: mean over the pixels and its Monte-Carlo error from the spread of 8 x 8 block means"""
+    h, w = img.shape[0] // 8 * 8, img.shape[1] // 8 * 8
+    a = np.nan_to_num(img[:h, :w, :3].astype(np.float64), nan=0.0, posinf=0.0, neginf=0.0)
+    blocks = a.reshape(h // 8, 8, w // 8, 8, 3).mean(axis=(1, 3)).reshape(-1, 3)
+    return a.mean(axis=(0, 1)), blocks.std(axis=0, ddof=1) / np.sqrt(blocks.shape[0])
+
+
+def test_environment_importance_sampling_converges_to_the_lookup_render(prt, oracle):
+    """prt_config::env_importance_sampling (north_star; NOT in the reference, which only looks the map up where a ray escapes): off by
+    default.  On: the expectation of every pixel must be the default mode's -- an open box under a sky with a sun, both modes converged,
+    image means within the Monte-Carlo error of their difference -- the noise must be lower (that is what it is for), and the device
+    code must equal its host compilation bit for bit (tests/emu: there is no oracle for a mode the reference does not have)."""
+    W, H, frames = 128, 96, 8192
+    scene = prt.HostScene("cornell_open.json")
+    cam = prt.default_camera(W, H)
+    env = prt.make_sky(256, 128)
+    res = {}
+    for mode in (0, 1):
+        cfg = scene.config()
+        cfg.env_importance_sampling = mode
+        imgs = []
+        for first in (1, 1 + frames):                                   # two independent renders per mode
+            r = prt.Renderer(cfg, device=0)
+            r.upload_scene(scene)
+            r.upload_envmap(env)
+            r.set_camera(cam)
+            r.resize(W, H)
+            r.render_frames(prt.seed_pairs(frames, first_frame=first))
+            imgs.append(r.read_framebuffer().astype(np.float64))
+            ran = r.kernel_variant()
+            r.close()
+        assert ("env_importance_sampling" in ran) == bool(mode), ran
+        m, e = _mean_and_error(0.5 * (imgs[0] + imgs[1]))
+        d = np.nan_to_num(imgs[0][..., :3] - imgs[1][..., :3])
+        res[mode] = (m, e, np.sqrt((d ** 2).mean()) / m.mean())
+    (m0, e0, n0), (m1, e1, n1) = res[0], res[1]
+    z = (m1 - m0) / np.sqrt(e0 ** 2 + e1 ** 2)
+    assert (np.abs(z) < 4.5).all() and (np.abs(m1 / m0 - 1.0) < 0.01).all(), "means %s vs %s (z = %s)" % (m0, m1, z)
+    assert n1 < 0.9 * n0, "noise with importance sampling %.4f, without %.4f" % (n1, n0)
+    # device == host compilation of the same code, bit for bit
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+    import emu_api
+    W2, H2, f2 = 29, 19, 96
+    cfg = scene.config()
+    cfg.env_importance_sampling = 1
+    cam2 = prt.default_camera(W2, H2)
+    seeds = prt.seed_pairs(f2)
+    small = prt.make_sky(64, 32)
+    hstate, himg = emu_api.render(oracle.PATH_STATE_DTYPE, cfg, scene.desc, cam2, W2, H2, seeds, env=small)
+    r = prt.Renderer(cfg, device=0)
+    r.upload_scene(scene)
+    r.upload_envmap(small)
+    r.set_camera(cam2)
+    r.resize(W2, H2)
+    r.render_frames(seeds)
+    _assert_same(oracle, hstate, himg, r.read_state(), r.read_framebuffer(), "env importance sampling: GPU vs host compilation")
+    r.close()
+    # refused where it is not built
+    bad = prt.HostScene("cornell_media.json")
+    cfgm = bad.config()
+    cfgm.env_importance_sampling = 1
+    rb = prt.Renderer(cfgm, device=0)
+    with pytest.raises(prt.PrtError, match="env_importance_sampling"):
+        rb.upload_scene(bad)
+    rb.close()
+
+
 def test_options_are_validated(prt):
     scene = prt.HostScene("cornell_diffuse.json")
     r = prt.Renderer(scene.config(), device=0)

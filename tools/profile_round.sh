@@ -24,11 +24,11 @@ for set in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SAL
   rm -rf $O/pmc_set$i
 done
 echo done; ls $O
-# the 871 k-triangle stand-in (BASELINE config 5 on one GPU, 1080p, few spp): where a big tree spends its time
+# the 871 k-triangle stand-in at BASELINE config 5's resolution (3840x2160, one GPU, few spp): where a big tree spends its time
 j=0
 for set in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_WAVES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum"; do
   j=$((j+1))
-  rocprofv3 --pmc $set --output-format csv -d $O/pmc_dragon$j -- python3 bench.py --no-cpu-baseline --scene cornell_dragon.json --spp 16 --steps 1 --warmup 0 > $O/pmc_dragon$j.log 2>&1
+  rocprofv3 --pmc $set --output-format csv -d $O/pmc_dragon$j -- python3 bench.py --no-cpu-baseline --scene cornell_dragon.json --width 3840 --height 2160 --spp 8 --steps 1 --warmup 0 > $O/pmc_dragon$j.log 2>&1
   python3 tools/pmc_sum.py $O/pmc_dragon$j > $O/pmc_dragon$j.json
   rm -rf $O/pmc_dragon$j
 done
