@@ -141,3 +141,37 @@ def test_axis_parallel_rays_nan_slabs(prt, oracle):
     assert oracle.state_fields_equal(rstate, state) == [] and oracle.images_equal(rimg, img)
     # premise (by construction, camera.cl:26-52): view.x = up.x = position.x = 0 -> hAxis = (+-1,0,0), vAxis.x = 0,
     # and at x = (W-1)/2 the factor 2*sx-1 is exactly 0, so origin.x = dir.x = 0 for the whole centre column
+
+
+LIBM_CASES = [("cornell_diffuse", "cornell_diffuse_libm", False, 0), ("cornell_roughcond", "cornell_roughcond_libm", True, 0),
+              ("cornell_media_hg", "cornell_media_hg_libm", True, 1)]
+
+
+@pytest.mark.parametrize("std,libm,use_env,phase", LIBM_CASES)
+def test_reference_build_with_glibc_math_agrees_as_an_estimate(prt, oracle, std, libm, use_env, phase):
+    """The reference's kernel text linked against TWO built-in libraries: include/prt_detmath.h (the stated one, shared by the restatement
+    and the HIP kernels) and, for the scalar transcendentals, the GNU C library's libm (oracle/ref/build_ref.py --math libm) -- math this
+    repository did not write.  Individual pixels part ways at the first decision an ulp flips; the ESTIMATE must not move: image means
+    within the Monte-Carlo error of their difference (full-length run: tools/independent_math.py -> profiles/r03_independent_math.txt)."""
+    if not (oracle.ref_available(std) and oracle.ref_available(libm)):
+        pytest.skip("reference build not present (development container only)")
+    size, frames = 48, 768
+    scene = prt.HostScene(VARIANTS[std][0])
+    cam = prt.default_camera(size, size)
+    seeds = prt.seed_pairs(frames)
+    env = prt.make_sky(64, 32) if use_env else None
+    imgs = []
+    for name in (std, libm):
+        _, img = oracle.RefOracle(name).render(scene.desc, bytes(cam), size, size, seeds, env=env, threads=8)
+        imgs.append(img.astype(np.float64)[..., :3])
+    a, b = imgs
+    finite = np.isfinite(a).all(axis=2) & np.isfinite(b).all(axis=2)
+    assert finite.mean() > 0.8                                # (the reference leaves NaN in some pixels of the medium scenes: 0 * inf in a weight)
+    same = ((a == b) | ~finite[..., None]).all(axis=2).mean()
+    assert 0.0 < same < 1.0                                   # some pixels never met a flipped decision, most did
+    d = np.where(finite[..., None], a - b, 0.0)
+    blocks = d.reshape(size // 8, 8, size // 8, 8, 3).mean(axis=(1, 3)).reshape(-1, 3)
+    sigma = blocks.std(axis=0, ddof=1) / np.sqrt(blocks.shape[0])
+    mean = np.where(finite[..., None], a, 0.0).mean(axis=(0, 1))
+    z = d.mean(axis=(0, 1)) / sigma
+    assert (np.abs(z) < 4.5).all() and (np.abs(d.mean(axis=(0, 1)) / mean) < 0.02).all(), "z = %s, relative difference of the means %s" % (z, d.mean(axis=(0, 1)) / mean)

@@ -114,17 +114,6 @@ static void* work2(void* arg) {
             ++j->n;
             if (err > j->max_ulp) { j->max_ulp = err; j->ax = x; j->ay = y; }
         }
-    printf("\ntwo-argument functions, 2^16 x 2^16 lattices of the argument ranges the path produces, against float64 libm\n");
-    printf("%-30s %14s %10s  %-28s %s\n", "function", "pairs", "max ulp", "at (first, second argument)", "domain");
-    for (unsigned k = 0; k < sizeof(CASES2) / sizeof(CASES2[0]); ++k) {
-        pthread_t th[NT];
-        Job2 jobs[NT];
-        for (int t = 0; t < NT; ++t) { jobs[t].c = &CASES2[k]; jobs[t].tid = t; pthread_create(&th[t], 0, work2, &jobs[t]); }
-        double mx = 0; float ax = 0, ay = 0; uint64_t n = 0;
-        for (int t = 0; t < NT; ++t) { pthread_join(th[t], 0); n += jobs[t].n; if (jobs[t].max_ulp > mx) { mx = jobs[t].max_ulp; ax = jobs[t].ax; ay = jobs[t].ay; } }
-        printf("%-30s %14llu %10.4f  (%-13a, %-13a) %s\n", CASES2[k].name, (unsigned long long)n, mx, ax, ay, CASES2[k].domain);
-        fflush(stdout);
-    }
     return 0;
 }
 
@@ -141,6 +130,17 @@ int main(int argc, char** argv) {
         char note[96] = "";
         if (CASES[k].exact) snprintf(note, sizeof note, "must be correctly rounded: %llu inputs are not", (unsigned long long)wrong);
         printf("%-18s %-34s %14llu %12.4f   0x%08x  %s\n", CASES[k].name, CASES[k].domain, (unsigned long long)n, mx, at, note);
+        fflush(stdout);
+    }
+    printf("\ntwo-argument functions, 2^16 x 2^16 lattices of the argument ranges the path produces, against float64 libm\n");
+    printf("%-30s %14s %10s  %-28s %s\n", "function", "pairs", "max ulp", "at (first, second argument)", "domain");
+    for (unsigned k = 0; k < sizeof(CASES2) / sizeof(CASES2[0]); ++k) {
+        pthread_t th[NT];
+        Job2 jobs[NT];
+        for (int t = 0; t < NT; ++t) { jobs[t].c = &CASES2[k]; jobs[t].tid = t; pthread_create(&th[t], 0, work2, &jobs[t]); }
+        double mx = 0; float ax = 0, ay = 0; uint64_t n = 0;
+        for (int t = 0; t < NT; ++t) { pthread_join(th[t], 0); n += jobs[t].n; if (jobs[t].max_ulp > mx) { mx = jobs[t].max_ulp; ax = jobs[t].ax; ay = jobs[t].ay; } }
+        printf("%-30s %14llu %10.4f  (%-13a, %-13a) %s\n", CASES2[k].name, (unsigned long long)n, mx, ax, ay, CASES2[k].domain);
         fflush(stdout);
     }
     return 0;
