@@ -179,9 +179,9 @@ int prt_render_spp(prt_ctx* ctx, uint32_t spp, uint32_t max_frames, const int32_
 /* Scheduling knob of the render kernel (no counterpart in the reference; results do not depend on it, tests check
  * that): a wave ends a BVH-walk phase once fewer than `lanes` of its 64 lanes are still walking (and fewer than wait for the
  * phase to end); the lanes cut off resume in the wave's next phase.  1 = every walk runs to its end (lock step).
- * Default: 8 (6 with a global medium and for launches with scattered pixels, 12 through big trees) for the closest-hit phases
+ * Default: 8 (6 with a global medium and for launches with scattered pixels, 16 through big trees) for the closest-hit phases
  * (PRT_WALK_MIN_LANES); for the shadow rays' any-hit
- * phases 1 in small trees and the same as above in big ones (PRT_SHADOW_MIN_LANES).  A call of this function sets both. */
+ * phases 1 in small trees and 12 in big ones (PRT_SHADOW_MIN_LANES).  A call of this function sets both. */
 int prt_set_walk_min_lanes(prt_ctx* ctx, uint32_t lanes);
 
 /* Build and schedule choices of a context (no counterpart in the reference; NONE changes a bit of any result -- the tests render
@@ -195,7 +195,7 @@ int prt_set_walk_min_lanes(prt_ctx* ctx, uint32_t lanes);
  *   "walk_min_lanes", "shadow_min_lanes"   0 (by launch) .. 64   see prt_set_walk_min_lanes
  *   "tri_q"             0 .. 16  the triangle tests that a walk phase's box steps found run once this many sixteenths of its walking
  *                               lanes have one pending (default 4)
- *   "frames_per_launch" >= 1    frames one launch of the render kernel covers (default 512)
+ *   "frames_per_launch" >= 0    frames one launch of the render kernel covers (0 = default: 512, or 4096 through a tree of more than 64 k node pairs)
  *   "run_ahead"         0 | 1   prt_render_spp: see there */
 int prt_set_option(prt_ctx* ctx, const char* name, int value);
 /* what the last launch ran, as text: "render_kernel<LIGHT|DIFF> waves=6 pixels=tiles" ("" before the first launch) */

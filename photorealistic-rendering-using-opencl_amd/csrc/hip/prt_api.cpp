@@ -57,7 +57,11 @@ struct prt_ctx {
     // frames a launch of render_kernel covers (PRT_FRAMES_PER_LAUNCH).  Lanes drift apart in frame number inside a launch
     // and the wave waits for its last lane at the end of each: long launches amortise that (cornell 1080p, MI355X:
     // 128 -> 7.85, 256 -> 8.18, 512 -> 8.33, 1024 -> 8.38, 2048 -> 8.08 G segments/s; 2 x 100 ms launches in flight at 512)
-    unsigned frames_per_launch = 512;
+    // Through a tree beyond one XCD's L2 the lanes of a wave drift much further apart (deep walks), and every launch boundary makes a wave
+    // wait for its slowest lane: 871 k triangles at 3840x2160, 512 spp: 512 -> 3.44, 1024 -> 3.57, 2048 -> 3.75, 4096 -> 3.84, 8192 -> 3.82 G
+    // segments/s (a launch of 4096 frames of that scene runs 7.5 s; cornell: 256 -> 12.74, 512 -> 12.85, 1024 -> 12.66).
+    // 0 = by tree size: 512, or 4096 beyond 64 k node pairs.
+    unsigned frames_per_launch = 0;
     // walk phases end below this many walking lanes (prt_set_walk_min_lanes, PRT_WALK_MIN_LANES; 0 = chosen per launch, pt_kernels.hip
     // launch_variant_w).  Round-2 kernel at 4 waves: 1 -> 7.78, 4 -> 8.33, 6 -> 8.37, 8 -> 8.28, 12 -> 7.98 G segments/s; at 5 waves:
     // 4 -> 10.65, 6 -> 11.36, 8 -> 11.45, 12 -> 11.4
@@ -386,7 +390,7 @@ extern "C" int prt_render_frames(prt_ctx* c, uint32_t first_frame, uint32_t n_fr
     c->stats.launches = 0; c->stats.frames = 0; c->stats.kernel_ms = 0.0; c->stats.kernel_sum_ms = 0.0; c->stats.concurrent = 1;
     if (!n_frames) return PRT_OK;
     if ((rc = ensure_seeds(c, seed_pairs, n_frames))) return rc;
-    const unsigned step = c->frames_per_launch;
+    const unsigned step = c->frames_per_launch ? c->frames_per_launch : (c->sc.n_pairs > 65536u ? 4096u : 512u);
     const int K = sub_parts(c);
     c->stats.concurrent = (uint32_t)K;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
@@ -416,7 +420,7 @@ extern "C" int prt_render_spp(prt_ctx* c, uint32_t spp, uint32_t max_frames, con
     HIPCHK(c, hipSetDevice(c->device));
     c->stats.launches = 0; c->stats.frames = 0; c->stats.kernel_ms = 0.0; c->stats.kernel_sum_ms = 0.0; c->stats.concurrent = 1;
     if ((rc = ensure_seeds(c, seed_pairs, max_frames))) return rc;
-    const unsigned step = c->frames_per_launch;
+    const unsigned step = c->frames_per_launch ? c->frames_per_launch : (c->sc.n_pairs > 65536u ? 4096u : 512u);
     const int K = sub_parts(c);
     c->stats.concurrent = (uint32_t)K;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
@@ -545,7 +549,7 @@ extern "C" int prt_set_option(prt_ctx* c, const char* name, int value) {
     else if (n == "walk_min_lanes") { if (value < 0 || value > 64) return bad(); c->walk_min_lanes = (uint32_t)value; }
     else if (n == "shadow_min_lanes") { if (value < 0 || value > 64) return bad(); c->shadow_min_lanes = (uint32_t)value; }
     else if (n == "tri_q") { if (value < 0 || value > 16) return bad(); c->tri_sixteenths = (uint32_t)value; }
-    else if (n == "frames_per_launch") { if (value < 1) return bad(); c->frames_per_launch = (unsigned)value; }
+    else if (n == "frames_per_launch") { if (value < 0) return bad(); c->frames_per_launch = (unsigned)value; }
     else if (n == "run_ahead") { if (value < 0 || value > 1) return bad(); c->run_ahead = (uint32_t)value; }
     else return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_set_option: unknown option " + n);
     return PRT_OK;

@@ -265,9 +265,10 @@ static void launch_variant_w(const DevScene& sc, const DevCamera& cam, const Dev
     // pixels, whose waves hold more deep walks (512x512 coat: 6 +4 %).  Shadow rays: in a small tree 99 % end at the root and the
     // rest is shallow -- cutting one off costs its pixel a whole iteration, letting the wave finish them costs a few steps (cornell
     // +3 %); through a big mesh they are as deep as any ray and the bound pays as it does for the closest-hit walks (+14 %).
-    // Through a tree beyond one XCD's L2: 12 (3840x2160: 8 -> 2.46, 12 -> 2.52, 16 -> 2.51 G segments/s).
-    if (!fb_args.walk_min_lanes) fb_args.walk_min_lanes = sc.n_pairs > 65536u ? 12u : ((MEDIUM || scatter) ? 6u : 8u);
-    if (!fb_args.shadow_min_lanes) fb_args.shadow_min_lanes = sc.n_pairs > 65536u ? fb_args.walk_min_lanes : 1u;
+    // Through a tree beyond one XCD's L2: 16 / 12 (3840x2160 x 512 spp, 4096 frames per launch: 12 / 12 -> 3.84, 16 / 16 -> 3.93, 16 / 12 -> 3.96 G
+    // segments/s; round 2, 512 frames per launch: 8 -> 2.46, 12 -> 2.52, 16 -> 2.51).
+    if (!fb_args.walk_min_lanes) fb_args.walk_min_lanes = sc.n_pairs > 65536u ? 16u : ((MEDIUM || scatter) ? 6u : 8u);
+    if (!fb_args.shadow_min_lanes) fb_args.shadow_min_lanes = sc.n_pairs > 65536u ? 12u : 1u;
     hipLaunchKernelGGL((render_kernel<MATS, MEDIUM, WAVES>), dim3(grid), dim3(PT_BLOCK), lds, stream, sc, cam, S, fb_args, fb);
 }
 // one material set x medium: picks the wave-count build and the pixel-to-wave mapping; reports both (RenderLaunch)

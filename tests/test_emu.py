@@ -147,3 +147,34 @@ def test_environment_importance_sampling_has_the_same_expectation_on_host(prt, o
     (m0, e0), (m1, e1) = out[0], out[1]
     z = (m1 - m0) / np.sqrt(e0 ** 2 + e1 ** 2)
     assert (np.abs(z) < 4.5).all() and (np.abs(m1 / m0 - 1.0) < 0.05).all(), "means %s vs %s (z = %s)" % (m0, m1, z)
+
+
+def callers_tree(prt, oracle):
+    """a CALLER'S tree, legal for the reference kernel but unlike anything the builder makes: loose boxes (the whole scene), a leaf of 40
+    triangles, two sibling leaves that SHARE triangles (ranges 20..59 and 30..99), 100 of the mesh's triangles referenced in all"""
+    import ctypes as C
+    scene = prt.HostScene("cornell_coat.json")
+    node_t = np.dtype([("bounds", "<f4", 6), ("first", "<u4"), ("count", "<u4"), ("leaf", "u1"), ("_p", "u1", 3)])
+    nodes = np.zeros(5, dtype=node_t)
+    nodes["bounds"] = np.array([-3, 3, -1, 5, -3, 3], dtype=np.float32)
+    nodes[0]["first"], nodes[0]["leaf"] = 1, 0                                   # root: children 1, 2
+    nodes[1]["first"], nodes[1]["count"], nodes[1]["leaf"] = 0, 40, 1            # a fat leaf
+    nodes[2]["first"], nodes[2]["leaf"] = 3, 0                                   # inner: children 3, 4
+    nodes[3]["first"], nodes[3]["count"], nodes[3]["leaf"] = 20, 40, 1
+    nodes[4]["first"], nodes[4]["count"], nodes[4]["leaf"] = 30, 70, 1
+    desc = prt.SceneDesc.from_buffer_copy(bytes(scene.desc))
+    desc.bvh_nodes = nodes.ctypes.data_as(C.c_void_p)
+    desc.bvh_node_count = len(nodes)
+    return scene, desc, nodes
+
+
+def test_callers_tree_with_shared_and_fat_leaves_on_host(prt, oracle, emu):
+    scene, desc, keep = callers_tree(prt, oracle)
+    W, H, frames = 24, 16, 12
+    cfg = scene.config()
+    cam = prt.default_camera(W, H)
+    seeds = prt.seed_pairs(frames)
+    ostate, oimg = oracle.Restatement().render(cfg, desc, cam, W, H, seeds, threads=4)
+    for sched in ((8, 0), (8, 99)):
+        state, img = emu.render(oracle.PATH_STATE_DTYPE, cfg, desc, cam, W, H, seeds, walk_min_lanes=sched[0], sched_seed=sched[1])
+        _same(oracle, ostate, oimg, state, img, "caller's tree, schedule %s" % (sched,))

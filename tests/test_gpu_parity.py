@@ -557,7 +557,7 @@ def test_options_are_validated(prt):
     scene = prt.HostScene("cornell_diffuse.json")
     r = prt.Renderer(scene.config(), device=0)
     assert r.kernel_variant() == ""
-    for name, value in (("waves", 4), ("waves", 7), ("scatter", 2), ("generic", 2), ("tri_q", 17), ("frames_per_launch", 0), ("no_such_option", 1)):
+    for name, value in (("waves", 4), ("waves", 7), ("scatter", 2), ("generic", 2), ("tri_q", 17), ("frames_per_launch", -1), ("no_such_option", 1)):
         with pytest.raises(prt.PrtError):
             r.set_option(name, value)
     r.close()
@@ -626,6 +626,25 @@ def _chain_bvh(levels):
     normals = np.zeros_like(verts)
     normals[:, 2] = 1.0
     return nodes, verts, normals, np.arange(tri, dtype=np.uint64)
+
+
+def test_callers_tree_with_shared_and_fat_leaves(prt, oracle):
+    """a tree the builder would never make but the reference kernel accepts: loose boxes, a 40-triangle leaf, sibling leaves that share
+    triangles (one slot per reference after packing; pending runs of 110 triangles)"""
+    from test_emu import callers_tree
+    scene, desc, keep = callers_tree(prt, oracle)
+    W, H, frames = 40, 24, 16
+    cfg = scene.config()
+    cam = prt.default_camera(W, H)
+    seeds = prt.seed_pairs(frames)
+    ostate, oimg = oracle.Restatement().render(cfg, desc, cam, W, H, seeds, threads=8)
+    r = prt.Renderer(cfg, device=0)
+    r.upload_scene(desc)
+    r.set_camera(cam)
+    r.resize(W, H)
+    r.render_frames(seeds)
+    _assert_same(oracle, ostate, oimg, r.read_state(), r.read_framebuffer(), "caller's tree")
+    r.close()
 
 
 @pytest.mark.parametrize("levels,ok", [(64, True), (65, False)])
