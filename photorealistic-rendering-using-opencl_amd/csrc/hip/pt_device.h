@@ -422,20 +422,6 @@ PT_DEV void walk_tri(const DevScene& sc, const bool ANY_HIT, const Ray& ray, Wal
     const float4 a = q[0], b = q[1], c4 = q[2];
     walk_tri_data(a, b, c4, ANY_HIT, ray, w);
 }
-// ONE unit of a lane's walk -- the box half of a step, or one pending triangle -- behind ONE memory access: a wave whose lanes are
-// at both kinds of unit waits for its loads once per iteration, not once per kind (the records are read through the same
-// instructions, the address is the lane's own)
-PT_DEV void walk_unit(const DevScene& sc, const bool ANY_HIT, const Ray& ray, const RayPre& p, WalkState& w, const TravStack& stack) {
-    const bool tri = w.pend_count != 0u;
-    const float4* q = tri ? reinterpret_cast<const float4*>(sc.tri_geom + w.pend_first) : reinterpret_cast<const float4*>(sc.pairs + w.node);
-    PairData d;
-    d.b0 = q[0]; d.b1 = q[1]; d.b2 = q[2];
-    d.meta = make_uint4(0u, 0u, 0u, 0u);
-    if (!tri) d.meta = *reinterpret_cast<const uint4*>(q + 3);
-    if (tri) walk_tri_data(d.b0, d.b1, d.b2, ANY_HIT, ray, w);
-    else walk_box_data(d, ANY_HIT, ray, p, w, stack);
-}
-
 // ---- sphere / quad, kernels/geometry/sphere.cl:5-41, quad.cl:11-38 ------------------------------
 PT_DEV bool hit_sphere(const DevSphere& s, const Ray& ray, float& best_t) {
     f3 p = ray.origin - ld3(s.pos);

@@ -37,9 +37,6 @@ using namespace dev;
 #ifndef PT_WAVES
 #define PT_WAVES 5
 #endif
-#ifndef PT_UNIFIED
-#define PT_UNIFIED 0        // a lane's box step and its pending triangle test share one load per iteration (0: box steps, then triangle tests)
-#endif
 #define PT_BLOCK 64         // threads per workgroup: ONE wave.  A workgroup's slot (LDS, dispatch) frees only when its last wave
                             // ends, and waves over the mesh run ~3x longer than waves over a wall: one-wave groups +4 % over 256
 
@@ -49,6 +46,9 @@ using namespace dev;
 //   are still walking; below that, stop as soon as more lanes wait for the phase to end (they finished their walk in it, or
 //   sit in the stage behind it) than walk.  A lane cut off keeps its WalkState and LDS stack and resumes in the same phase
 //   of the next iteration.
+//   triangle rule: inside a walk phase a lane alternates between box steps (walk_box) and the triangles those found (walk_tri, one
+//   per call: pt_device.h "deferred leaves"); the wave runs the triangle unit once fa.tri_sixteenths / 16 of the lanes in the loop
+//   have one pending, or when the phase is about to end -- it ran for 1.7 lanes of 64 when every box step carried its own loop.
 //   run-ahead ("N spp" launches, fa.run_ahead): a lane that has done its n_frames starts on the next launch's frames for as
 //   long as another lane of the wave still owes frames of this one; its lead goes into the state (q4.w >> 2).
 // WAVES = waves per SIMD the register allocator leaves room for.
@@ -122,19 +122,6 @@ __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene 
             const unsigned n_start = (unsigned)__popcll(__ballot(go));
             const unsigned n_other = (unsigned)__popcll(__ballot((walking && L.w.done) || L.stage == ST_BACK));
             if (go) {
-#if PT_UNIFIED
-                // every iteration a lane takes ONE unit of its walk (the box half of a step, or one pending triangle) behind one
-                // load; the lanes with a triangle pending sit iterations out until enough of the phase's lanes have one (the first
-                // iteration of a phase takes them anyway: a pending lane tests at least one triangle per iteration of the wave)
-                for (bool first = true;; first = false) {
-                    const bool pending = L.w.pend_count != 0u;
-                    const unsigned n_in = (unsigned)__popcll(__ballot(1)), n_pend = (unsigned)__popcll(__ballot(pending));
-                    if (!pending || first || n_pend * 16u >= n_in * TQ) walk_unit(sc, false, wr, p, L.w, stk);
-                    if (L.w.done) break;
-                    const unsigned n_act = (unsigned)__popcll(__ballot(1));
-                    if (n_act < T && n_other + (n_start - n_act) > PT_WAIT_RATIO * n_act) break;   // the lanes that wait outnumber the walkers
-                }
-#else
                 for (;;) {
                     if (!L.w.pend_count) walk_box(sc, false, wr, p, L.w, stk);
                     // the triangles that the box steps found are tested once enough of the walking lanes have one pending (or the
@@ -146,7 +133,6 @@ __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene 
                     if (pending && (n_pend * 16u >= n_in * TQ || cut)) walk_tri(sc, false, wr, L.w);
                     if (L.w.done || cut) break;
                 }
-#endif
             }
             PT_CLK(1);
             if (walking && L.w.done) { PT_WSTAT(5); lane_closest_done<MATS, MEDIUM>(sc, L); }
@@ -163,19 +149,6 @@ __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene 
             const unsigned n_start = (unsigned)__popcll(__ballot(go));
             const unsigned n_other = (unsigned)__popcll(__ballot((walking && L.w.done) || L.stage == ST_FINISH));
             if (go) {
-#if PT_UNIFIED
-                // every iteration a lane takes ONE unit of its walk (the box half of a step, or one pending triangle) behind one
-                // load; the lanes with a triangle pending sit iterations out until enough of the phase's lanes have one (the first
-                // iteration of a phase takes them anyway: a pending lane tests at least one triangle per iteration of the wave)
-                for (bool first = true;; first = false) {
-                    const bool pending = L.w.pend_count != 0u;
-                    const unsigned n_in = (unsigned)__popcll(__ballot(1)), n_pend = (unsigned)__popcll(__ballot(pending));
-                    if (!pending || first || n_pend * 16u >= n_in * TQ) walk_unit(sc, true, wr, p, L.w, stk);
-                    if (L.w.done) break;
-                    const unsigned n_act = (unsigned)__popcll(__ballot(1));
-                    if (n_act < TD && n_other + (n_start - n_act) > PT_WAIT_RATIO * n_act) break;   // the lanes that wait outnumber the walkers
-                }
-#else
                 for (;;) {
                     if (!L.w.pend_count) walk_box(sc, true, wr, p, L.w, stk);
                     const bool pending = L.w.pend_count != 0u;
@@ -185,7 +158,6 @@ __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene 
                     if (pending && (n_pend * 16u >= n_in * TQ || cut)) walk_tri(sc, true, wr, L.w);
                     if (L.w.done || cut) break;
                 }
-#endif
             }
             if (walking && L.w.done) { L.occluded = L.w.found; L.stage = ST_FINISH; }
         }

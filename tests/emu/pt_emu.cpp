@@ -86,25 +86,26 @@ void run_tile(const DevScene& sc, const DevCamera& cam, const FrameArgs& fa, int
         }
         const unsigned T = phase_T();
         const unsigned TQ = sched_seed ? xs.next() % 17u : fa.tri_sixteenths;        // a random share of pending lanes starts the triangle tests
-        for (bool first = true;; first = false) {
-            // render_kernel's loop: every iteration a lane takes one unit of its walk (walk_unit: the box half of a step, or one
-            // pending triangle); lanes with a triangle pending sit iterations out until enough of the lanes in the loop have one
-            unsigned n_in = 0, n_pend = 0;
+        for (;;) {
+            // render_kernel's loop: box steps of the lanes without a pending triangle, then -- once enough of the lanes in the loop
+            // have one, or the phase is about to end -- one triangle of every pending lane
+            unsigned n_in = 0, n_pend = 0, n_act = 0;
             for (int lane = 0; lane < 64; ++lane) {
                 if (!go[lane]) continue;
                 ++n_in;
+                if (!L[lane].w.pend_count) walk_box(sc, any_hit, wr[lane], p[lane], L[lane].w, stk[lane]);
                 if (L[lane].w.pend_count) ++n_pend;
+                if (!L[lane].w.done) ++n_act;
             }
             if (!n_in) break;
-            const bool tri = first || n_pend * 16u >= n_in * TQ;
-            unsigned n_act = 0;
+            const bool cut = n_act < T && n_other + (n_start - n_act) > n_act;      // render_kernel's rule (PT_WAIT_RATIO 1)
+            const bool tri = n_pend * 16u >= n_in * TQ || cut;
             for (int lane = 0; lane < 64; ++lane) {
                 if (!go[lane]) continue;
-                if (!L[lane].w.pend_count || tri) walk_unit(sc, any_hit, wr[lane], p[lane], L[lane].w, stk[lane]);
-                if (L[lane].w.done) go[lane] = false; else ++n_act;
+                if (tri && L[lane].w.pend_count) walk_tri(sc, any_hit, wr[lane], L[lane].w);
+                if (L[lane].w.done) go[lane] = false;
             }
-            if (n_act == 0) break;
-            if (n_act < T && n_other + (n_start - n_act) > n_act) break;      // render_kernel's rule (PT_WAIT_RATIO 1)
+            if (cut) break;
         }
     };
 
