@@ -1,6 +1,8 @@
 #include "model_loader.h"
 
+#include <cctype>
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -29,7 +31,44 @@ bool ModelLoader::ImportFromFile(const std::string& path) {
         err_ = "cannot open model '" + path + "'";
         return false;
     }
+    std::string low = path;
+    for (char& ch : low) ch = (char)std::tolower((unsigned char)ch);
+    if (ends_with(low, ".ply")) return load_ply(path);
+    if (ends_with(low, ".stl")) return load_stl(path);
     return load_obj(path);
+}
+
+static float3 unit_face_normal(const float3& a, const float3& b, const float3& c) {
+    float ux = b.x - a.x, uy = b.y - a.y, uz = b.z - a.z, vx = c.x - a.x, vy = c.y - a.y, vz = c.z - a.z;
+    float3 n{uy * vz - uz * vy, uz * vx - ux * vz, ux * vy - uy * vx};
+    float l = sqrtf(n.x * n.x + n.y * n.y + n.z * n.z);
+    if (l > 0.f) { n.x /= l; n.y /= l; n.z /= l; }
+    return n;
+}
+
+// Faces that came without normals (their corners hold the unit geometric normal): the reference imports with
+// aiProcessPreset_TargetRealtime_Quality (src/Models/model_loader.cpp:38), whose GenSmoothNormals step gives every vertex the
+// normalised sum of the unit normals of the faces that meet at its position (smoothing-angle limit 175 degrees).  Same rule here, on
+// bit-identical positions (assimp is an absent submodule, so this step has no oracle: SURVEY s8f row N2).  The preset's
+// JoinIdenticalVertices has no effect on this path: the renderer de-indexes every mesh into a triangle soup (src/main.cpp:93-119).
+static void smooth_missing_normals(Mesh& mesh, const std::vector<size_t>& needs_normals) {
+    if (needs_normals.empty()) return;
+    struct Key { uint32_t x, y, z; bool operator<(const Key& o) const { return x != o.x ? x < o.x : (y != o.y ? y < o.y : z < o.z); } };
+    auto key = [](const float3& p) { Key k; float z0 = p.x + 0.0f, z1 = p.y + 0.0f, z2 = p.z + 0.0f;      // -0 -> +0
+                                     std::memcpy(&k.x, &z0, 4); std::memcpy(&k.y, &z1, 4); std::memcpy(&k.z, &z2, 4); return k; };
+    std::map<Key, std::vector<float3>> at;               // position -> unit normals of the faces around it
+    for (size_t fi : needs_normals)
+        for (auto& p : mesh.faces[fi].points) at[key(p.pos)].push_back(p.nor);
+    const float cos_limit = -0.99619470f;                // cos(175 deg)
+    for (size_t fi : needs_normals)
+        for (auto& p : mesh.faces[fi].points) {
+            const float3 own = p.nor;
+            float sx = 0.f, sy = 0.f, sz = 0.f;
+            for (const float3& n : at[key(p.pos)])
+                if (n.x * own.x + n.y * own.y + n.z * own.z >= cos_limit) { sx += n.x; sy += n.y; sz += n.z; }
+            const float l = sqrtf(sx * sx + sy * sy + sz * sz);
+            if (l > 0.f) p.nor = {sx / l, sy / l, sz / l};
+        }
 }
 
 size_t ModelLoader::triangleCount() const {
@@ -95,11 +134,7 @@ bool ModelLoader::load_obj(const std::string& path) {
                 }
                 if (cs[0].n == 0 || cs[k].n == 0 || cs[k + 1].n == 0) {
                     // no vn: unit geometric normal for now, smoothed over the faces that share a position below
-                    const float3 &a = face.points[0].pos, &b = face.points[1].pos, &c = face.points[2].pos;
-                    float ux = b.x - a.x, uy = b.y - a.y, uz = b.z - a.z, vx = c.x - a.x, vy = c.y - a.y, vz = c.z - a.z;
-                    float3 n{uy * vz - uz * vy, uz * vx - ux * vz, ux * vy - uy * vx};
-                    float l = sqrtf(n.x * n.x + n.y * n.y + n.z * n.z);
-                    if (l > 0.f) { n.x /= l; n.y /= l; n.z /= l; }
+                    const float3 n = unit_face_normal(face.points[0].pos, face.points[1].pos, face.points[2].pos);
                     for (auto& p : face.points) p.nor = n;
                     needs_normals.push_back(mesh.faces.size());
                 }
@@ -108,28 +143,192 @@ bool ModelLoader::load_obj(const std::string& path) {
         }
     }
     if (mesh.faces.empty()) { err_ = "no faces in '" + path + "'"; return false; }
-    // Files without vn records: the reference imports with aiProcessPreset_TargetRealtime_Quality
-    // (src/Models/model_loader.cpp:38), whose GenSmoothNormals step gives every vertex the normalised sum of the
-    // unit normals of the faces that meet at its position (smoothing-angle limit 175 degrees).  Same rule here, on
-    // bit-identical positions (assimp is an absent submodule, so this step has no oracle: SURVEY s8f row N2).
-    if (!needs_normals.empty()) {
-        struct Key { uint32_t x, y, z; bool operator<(const Key& o) const { return x != o.x ? x < o.x : (y != o.y ? y < o.y : z < o.z); } };
-        auto key = [](const float3& p) { Key k; float z0 = p.x + 0.0f, z1 = p.y + 0.0f, z2 = p.z + 0.0f;      // -0 -> +0
-                                         std::memcpy(&k.x, &z0, 4); std::memcpy(&k.y, &z1, 4); std::memcpy(&k.z, &z2, 4); return k; };
-        std::map<Key, std::vector<float3>> at;               // position -> unit normals of the faces around it
-        for (size_t fi : needs_normals)
-            for (auto& p : mesh.faces[fi].points) at[key(p.pos)].push_back(p.nor);
-        const float cos_limit = -0.99619470f;                // cos(175 deg)
-        for (size_t fi : needs_normals)
-            for (auto& p : mesh.faces[fi].points) {
-                const float3 own = p.nor;
-                float sx = 0.f, sy = 0.f, sz = 0.f;
-                for (const float3& n : at[key(p.pos)])
-                    if (n.x * own.x + n.y * own.y + n.z * own.z >= cos_limit) { sx += n.x; sy += n.y; sz += n.z; }
-                const float l = sqrtf(sx * sx + sy * sy + sz * sz);
-                if (l > 0.f) p.nor = {sx / l, sy / l, sz / l};
-            }
+    smooth_missing_normals(mesh, needs_normals);           // files without vn records
+    scene_.meshes.push_back(std::move(mesh));
+    return true;
+}
+
+// ---- Stanford PLY (ascii 1.0 / binary_little_endian 1.0): element vertex {x y z [nx ny nz] ...}, element face {list <count> <index>
+// vertex_indices | vertex_index ...}; other elements and properties are skipped; polygons fan-triangulated; without normals: as an
+// OBJ without vn.  One of the formats the reference reaches through assimp (src/Models/model_loader.cpp:38).
+namespace {
+struct PlyProp { std::string name; int type = 0, count_type = -1; };      // type: index into PLY_SIZES; count_type >= 0: a list
+const char* const PLY_TYPES[] = {"char", "int8", "uchar", "uint8", "short", "int16", "ushort", "uint16", "int", "int32", "uint", "uint32", "float", "float32", "double", "float64"};
+const int PLY_SIZES[] = {1, 1, 1, 1, 2, 2, 2, 2, 4, 4, 4, 4, 4, 4, 8, 8};
+int ply_type(const std::string& t) { for (int k = 0; k < 16; ++k) if (t == PLY_TYPES[k]) return k; return -1; }
+struct PlyElem { std::string name; size_t count = 0; std::vector<PlyProp> props; };
+// one scalar of PLY type `t`, from text or from little-endian bytes; false at the end of the data
+bool ply_scalar(std::istream& f, bool ascii, int t, double& out) {
+    if (ascii) { return (bool)(f >> out); }
+    unsigned char b[8];
+    f.read(reinterpret_cast<char*>(b), PLY_SIZES[t]);
+    if (!f) return false;
+    switch (t / 2) {
+        case 0: out = (double)(int8_t)b[0]; break;
+        case 1: out = (double)b[0]; break;
+        case 2: { int16_t v; std::memcpy(&v, b, 2); out = v; break; }
+        case 3: { uint16_t v; std::memcpy(&v, b, 2); out = v; break; }
+        case 4: { int32_t v; std::memcpy(&v, b, 4); out = v; break; }
+        case 5: { uint32_t v; std::memcpy(&v, b, 4); out = v; break; }
+        case 6: { float v; std::memcpy(&v, b, 4); out = v; break; }
+        default: { double v; std::memcpy(&v, b, 8); out = v; break; }
     }
+    return true;
+}
+}  // namespace
+
+bool ModelLoader::load_ply(const std::string& path) {
+    std::ifstream f(path, std::ios::binary);
+    std::string line;
+    if (!std::getline(f, line) || line.substr(0, 3) != "ply") { err_ = "not a PLY file: '" + path + "'"; return false; }
+    bool ascii = false, have_format = false;
+    std::vector<PlyElem> elems;
+    while (std::getline(f, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        std::istringstream ls(line);
+        std::string w;
+        ls >> w;
+        if (w == "format") {
+            std::string fmt; ls >> fmt;
+            if (fmt == "ascii") ascii = true;
+            else if (fmt != "binary_little_endian") { err_ = "unsupported PLY format '" + fmt + "' in '" + path + "'"; return false; }
+            have_format = true;
+        } else if (w == "element") {
+            PlyElem e; ls >> e.name >> e.count;
+            elems.push_back(e);
+        } else if (w == "property") {
+            if (elems.empty()) { err_ = "PLY property before any element in '" + path + "'"; return false; }
+            PlyProp p; std::string t; ls >> t;
+            if (t == "list") { std::string ct, it; ls >> ct >> it >> p.name; p.count_type = ply_type(ct); p.type = ply_type(it); if (p.count_type < 0) p.type = -1; }
+            else { p.type = ply_type(t); ls >> p.name; }
+            if (p.type < 0) { err_ = "unknown PLY property type in '" + path + "'"; return false; }
+            elems.back().props.push_back(p);
+        } else if (w == "end_header") break;
+    }
+    if (!have_format) { err_ = "PLY header without a format line in '" + path + "'"; return false; }
+    std::vector<float3> pos, nor;
+    bool have_normals = false;
+    Mesh mesh;
+    std::vector<size_t> needs_normals;
+    for (const PlyElem& e : elems) {
+        if (e.count > (size_t)1 << 31) { err_ = "unreasonable element count in '" + path + "'"; return false; }
+        int ix = -1, iy = -1, iz = -1, inx = -1, iny = -1, inz = -1;
+        if (e.name == "vertex") {
+            for (size_t k = 0; k < e.props.size(); ++k) {
+                const std::string& n = e.props[k].name;
+                if (n == "x") ix = (int)k; else if (n == "y") iy = (int)k; else if (n == "z") iz = (int)k;
+                else if (n == "nx") inx = (int)k; else if (n == "ny") iny = (int)k; else if (n == "nz") inz = (int)k;
+            }
+            if (ix < 0 || iy < 0 || iz < 0) { err_ = "PLY vertex element without x / y / z in '" + path + "'"; return false; }
+            have_normals = inx >= 0 && iny >= 0 && inz >= 0;
+        }
+        for (size_t r = 0; r < e.count; ++r) {
+            float3 p, n;
+            std::vector<long> idx;
+            for (size_t k = 0; k < e.props.size(); ++k) {
+                const PlyProp& pr = e.props[k];
+                double v = 0.0;
+                if (pr.count_type >= 0) {
+                    if (!ply_scalar(f, ascii, pr.count_type, v) || v < 0 || v > 1e6) { err_ = "truncated or corrupt PLY data in '" + path + "'"; return false; }
+                    const long cnt = (long)v;
+                    const bool is_index = e.name == "face" && (pr.name == "vertex_indices" || pr.name == "vertex_index");
+                    for (long c = 0; c < cnt; ++c) {
+                        if (!ply_scalar(f, ascii, pr.type, v)) { err_ = "truncated PLY data in '" + path + "'"; return false; }
+                        if (is_index) idx.push_back((long)v);
+                    }
+                    continue;
+                }
+                if (!ply_scalar(f, ascii, pr.type, v)) { err_ = "truncated PLY data in '" + path + "'"; return false; }
+                const int kk = (int)k;
+                if (kk == ix) p.x = (float)v; else if (kk == iy) p.y = (float)v; else if (kk == iz) p.z = (float)v;
+                else if (kk == inx) n.x = (float)v; else if (kk == iny) n.y = (float)v; else if (kk == inz) n.z = (float)v;
+            }
+            if (e.name == "vertex") {
+                if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) { err_ = "non-finite vertex position in '" + path + "'"; return false; }
+                pos.push_back(p); nor.push_back(n);
+            } else if (e.name == "face") {
+                for (size_t k = 1; k + 1 < idx.size(); ++k) {
+                    Face face;
+                    const long tri[3] = {idx[0], idx[k], idx[k + 1]};
+                    for (int c = 0; c < 3; ++c) {
+                        if (tri[c] < 0 || tri[c] >= (long)pos.size()) { err_ = "face index out of range in '" + path + "'"; return false; }
+                        face.points[c].pos = pos[(size_t)tri[c]];
+                        face.points[c].nor = nor[(size_t)tri[c]];
+                    }
+                    if (!have_normals) {
+                        const float3 gn = unit_face_normal(face.points[0].pos, face.points[1].pos, face.points[2].pos);
+                        for (auto& q : face.points) q.nor = gn;
+                        needs_normals.push_back(mesh.faces.size());
+                    }
+                    mesh.faces.push_back(face);
+                }
+            }
+        }
+    }
+    if (mesh.faces.empty()) { err_ = "no faces in '" + path + "'"; return false; }
+    smooth_missing_normals(mesh, needs_normals);
+    scene_.meshes.push_back(std::move(mesh));
+    return true;
+}
+
+// ---- STL: binary (80-byte header, uint32 count, 50 bytes per facet) or ASCII ("facet normal .. outer loop vertex ..").  A facet's
+// own normal is used for its three corners when it is finite and non-zero (flat shading, what an importer hands on for this format),
+// the unit geometric normal otherwise.
+bool ModelLoader::load_stl(const std::string& path) {
+    std::ifstream f(path, std::ios::binary);
+    f.seekg(0, std::ios::end);
+    const std::streamoff size = f.tellg();
+    f.seekg(0);
+    Mesh mesh;
+    auto add = [&](const float* n, const float* v) -> bool {
+        Face face;
+        for (int c = 0; c < 3; ++c) {
+            if (!std::isfinite(v[3 * c]) || !std::isfinite(v[3 * c + 1]) || !std::isfinite(v[3 * c + 2])) return false;
+            face.points[c].pos = {v[3 * c], v[3 * c + 1], v[3 * c + 2]};
+        }
+        float3 fn{n[0], n[1], n[2]};
+        const float l = sqrtf(fn.x * fn.x + fn.y * fn.y + fn.z * fn.z);
+        if (!(l > 0.f) || !std::isfinite(l)) fn = unit_face_normal(face.points[0].pos, face.points[1].pos, face.points[2].pos);
+        for (auto& p : face.points) p.nor = fn;
+        mesh.faces.push_back(face);
+        return true;
+    };
+    uint32_t count = 0;
+    if (size >= 84) {
+        char header[80];
+        f.read(header, 80);
+        f.read(reinterpret_cast<char*>(&count), 4);
+    }
+    if (size >= 84 && (uint64_t)count * 50u + 84u == (uint64_t)size) {           // binary: the size says so (an ASCII file may start with "solid" too)
+        std::vector<unsigned char> buf((size_t)count * 50);
+        f.read(reinterpret_cast<char*>(buf.data()), (std::streamsize)buf.size());
+        if (!f) { err_ = "truncated STL '" + path + "'"; return false; }
+        for (uint32_t i = 0; i < count; ++i) {
+            float v[12];
+            std::memcpy(v, &buf[(size_t)i * 50], 48);
+            if (!add(v, v + 3)) { err_ = "non-finite vertex position in '" + path + "'"; return false; }
+        }
+    } else {
+        f.clear();
+        f.seekg(0);
+        std::string w;
+        float n[3] = {0, 0, 0}, v[9];
+        int nv = 0;
+        while (f >> w) {
+            if (w == "facet") { std::string kw; f >> kw >> n[0] >> n[1] >> n[2]; nv = 0; if (!f) break; }
+            else if (w == "vertex") {
+                if (nv >= 3) { err_ = "STL facet with more than three vertices in '" + path + "'"; return false; }
+                f >> v[3 * nv] >> v[3 * nv + 1] >> v[3 * nv + 2];
+                if (!f) break;
+                ++nv;
+            } else if (w == "endfacet") {
+                if (nv != 3) { err_ = "STL facet without three vertices in '" + path + "'"; return false; }
+                if (!add(n, v)) { err_ = "non-finite vertex position in '" + path + "'"; return false; }
+                nv = 0;
+            }
+        }
+    }
+    if (mesh.faces.empty()) { err_ = "no facets in '" + path + "'"; return false; }
     scene_.meshes.push_back(std::move(mesh));
     return true;
 }

@@ -1,8 +1,9 @@
 // model_loader.h -- triangle-soup loader with the reference's Scene{meshes{faces{points{pos,nor}}}}
 // view (include/Model/model_loader.h:21-62).  The reference imports through assimp
 // (src/Models/model_loader.cpp:38), which is not available; this loader reads Wavefront OBJ
-// (v / vn / f, fan-triangulated polygons, negative indices) and the ".prtmesh" binary soup
-// ("PRTMESH1", uint32 triangle_count, then per triangle 3 x {pos xyz, nor xyz} float32).
+// (v / vn / f, fan-triangulated polygons, negative indices), Stanford PLY (ascii / binary little-endian), STL (ascii / binary) and
+// the ".prtmesh" binary soup ("PRTMESH1", uint32 triangle_count, then per triangle 3 x {pos xyz, nor xyz} float32).  All meshes /
+// groups of a file are flattened into one triangle list, as ModelLoader::getFaces' only user does (src/main.cpp:93-119).
 #pragma once
 #include <array>
 #include <memory>
@@ -32,6 +33,8 @@ public:
 
 private:
     bool load_obj(const std::string& path);
+    bool load_ply(const std::string& path);
+    bool load_stl(const std::string& path);
     bool load_soup(const std::string& path);
     Scene scene_;
     std::string err_;

@@ -157,6 +157,87 @@ def test_obj_reader_and_soup_roundtrip(prt, tmp_path):
     assert lib.prth_convert_model(b"/nonexistent.obj", str(soup).encode(), err, 256) != 0
 
 
+def _octahedron():
+    v = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], dtype=np.float32) * np.float32(0.37)
+    f = [[0, 2, 4], [2, 1, 4], [1, 3, 4], [3, 0, 4], [2, 0, 5], [1, 2, 5], [3, 1, 5], [0, 3, 5]]
+    return v, f
+
+
+def _soup(prt, path, tmp_path):
+    lib = prt.load_library()
+    err = C.create_string_buffer(256)
+    out = str(tmp_path / (os.path.basename(path) + ".prtmesh"))
+    rc = lib.prth_convert_model(str(path).encode(), out.encode(), err, 256)
+    if rc:
+        raise prt.PrtError(err.value.decode())
+    raw = open(out, "rb").read()
+    return np.frombuffer(raw[12:], dtype=np.float32).reshape(-1, 3, 6)
+
+
+def test_ply_and_stl_readers_agree_with_the_obj_reader(prt, tmp_path):
+    """formats the reference reaches through assimp (src/Models/model_loader.cpp:38; "next" row N2): Stanford PLY, ascii and binary
+    little-endian, with and without normals, a quad face, an extra element and extra properties to skip; STL, binary and ascii.  The
+    same mesh through every reader must give the same triangle soup as the OBJ reader (positions bit for bit; generated normals by
+    the same smoothing rule; file normals as written)."""
+    v, f = _octahedron()
+    vn = (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+    obj = tmp_path / "o.obj"
+    obj.write_text("".join("v %r %r %r\n" % tuple(float(x) for x in p) for p in v) + "".join("f %d %d %d\n" % tuple(i + 1 for i in t) for t in f))
+    objn = tmp_path / "on.obj"
+    objn.write_text("".join("v %r %r %r\n" % tuple(float(x) for x in p) for p in v) + "".join("vn %r %r %r\n" % tuple(float(x) for x in p) for p in vn) +
+                    "".join("f %d//%d %d//%d %d//%d\n" % (t[0] + 1, t[0] + 1, t[1] + 1, t[1] + 1, t[2] + 1, t[2] + 1) for t in f))
+    want, want_n = _soup(prt, obj, tmp_path), _soup(prt, objn, tmp_path)
+    assert want.shape == (8, 3, 6)
+    # ascii PLY without normals, the first two triangles merged into one quad face (fan-triangulated back), an extra property
+    quad = [[0, 2, 1, 4]] if False else None
+    ply = tmp_path / "a.ply"
+    ply.write_text("ply\nformat ascii 1.0\ncomment made by tests\nelement vertex 6\nproperty float x\nproperty float y\nproperty float z\nproperty uchar red\n"
+                   "element face 8\nproperty list uchar int vertex_indices\nend_header\n" +
+                   "".join("%r %r %r 255\n" % tuple(float(x) for x in p) for p in v) + "".join("3 %d %d %d\n" % tuple(t) for t in f))
+    assert np.array_equal(_soup(prt, ply, tmp_path).view(np.uint32), want.view(np.uint32))
+    # binary PLY with normals, double-precision positions, an element to skip in front, ushort list counts
+    head = ("ply\nformat binary_little_endian 1.0\nelement camera 1\nproperty float fov\nproperty list uchar float extra\n"
+            "element vertex 6\nproperty double x\nproperty double y\nproperty double z\nproperty float nx\nproperty float ny\nproperty float nz\n"
+            "element face 8\nproperty list ushort uint vertex_index\nend_header\n").encode()
+    body = struct.pack("<fB2f", 45.0, 2, 1.0, 2.0)
+    for p, n in zip(v, vn):
+        body += struct.pack("<3d3f", *[float(x) for x in p], *[float(x) for x in n])
+    for t in f:
+        body += struct.pack("<H3I", 3, *t)
+    plyb = tmp_path / "b.ply"
+    plyb.write_bytes(head + body)
+    assert np.array_equal(_soup(prt, plyb, tmp_path).view(np.uint32), want_n.view(np.uint32))
+    # a quad face: fan (0 1 2 3) -> (0 1 2), (0 2 3)
+    plyq = tmp_path / "q.ply"
+    plyq.write_text("ply\nformat ascii 1.0\nelement vertex 4\nproperty float x\nproperty float y\nproperty float z\nelement face 1\n"
+                    "property list uchar int vertex_indices\nend_header\n0 0 0\n1 0 0\n1 1 0\n0 1 0\n4 0 1 2 3\n")
+    q = _soup(prt, plyq, tmp_path)
+    assert q.shape == (2, 3, 6) and np.array_equal(q[1, :, :3], [[0, 0, 0], [1, 1, 0], [0, 1, 0]]) and np.array_equal(q[:, :, 3:], np.tile([0, 0, 1], (2, 3, 1)))
+    # STL: binary with facet normals (kept, flat), ascii with zero normals (geometric)
+    tri = v[np.array(f)]                                            # [8, 3, 3]
+    fn = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+    fn = (fn / np.linalg.norm(fn, axis=1, keepdims=True)).astype(np.float32)
+    stl = tmp_path / "b.stl"
+    stl.write_bytes(b"solid looks like ascii but is not".ljust(80, b" ") + struct.pack("<I", 8) +
+                    b"".join(struct.pack("<12fH", *fn[k], *tri[k].ravel(), 0) for k in range(8)))
+    sb = _soup(prt, stl, tmp_path)
+    assert np.array_equal(sb[:, :, :3].view(np.uint32), want[:, :, :3].view(np.uint32))
+    assert np.array_equal(sb[:, :, 3:], np.repeat(fn[:, None, :], 3, axis=1))
+    stla = tmp_path / "a.stl"
+    stla.write_text("solid t\n" + "".join("facet normal 0 0 0\n outer loop\n" + "".join("  vertex %r %r %r\n" % tuple(float(x) for x in p) for p in tri[k]) +
+                                           " endloop\nendfacet\n" for k in range(8)) + "endsolid t\n")
+    sa = _soup(prt, stla, tmp_path)
+    assert np.array_equal(sa[:, :, :3].view(np.uint32), want[:, :, :3].view(np.uint32))
+    assert np.abs(sa[:, :, 3:] - np.repeat(fn[:, None, :], 3, axis=1)).max() < 1e-6
+    # damaged files are errors, not crashes
+    for name, data in (("t.ply", head + body[:40]), ("e.ply", b"ply\nformat binary_big_endian 1.0\nend_header\n"), ("i.ply", ply.read_text().replace("3 0 2 4", "3 0 2 9").encode()),
+                       ("t.stl", stl.read_bytes()[:200]), ("n.stl", b"solid x\nfacet normal 0 0 0\nouter loop\nvertex 0 0 0\nvertex nan 0 0\nvertex 0 1 0\nendloop\nendfacet\n")):
+        bad = tmp_path / name
+        bad.write_bytes(data)
+        with pytest.raises(prt.PrtError):
+            _soup(prt, bad, tmp_path)
+
+
 def test_malformed_scene_text_is_an_error_not_a_crash(prt):
     """truncated / mistyped scene files come back as load errors; out-of-range `type` / `dist` exponents (the
     reference shifts by them unchecked, include/Scene/scene.h:90-101) give an empty bit, not undefined behaviour"""
