@@ -239,7 +239,7 @@ static void launch_variant_w(const DevScene& sc, const DevCamera& cam, const Dev
     // +3 %); through a big mesh they are as deep as any ray and the bound pays as it does for the closest-hit walks (+14 %).
     // Through a tree beyond one XCD's L2: 16 / 12 (3840x2160 x 512 spp, 4096 frames per launch: 12 / 12 -> 3.84, 16 / 16 -> 3.93, 16 / 12 -> 3.96 G
     // segments/s; round 2, 512 frames per launch: 8 -> 2.46, 12 -> 2.52, 16 -> 2.51).
-    if (!fb_args.walk_min_lanes) fb_args.walk_min_lanes = sc.n_pairs > 65536u ? 16u : ((MEDIUM || scatter) ? 6u : 8u);
+    if (!fb_args.walk_min_lanes) fb_args.walk_min_lanes = sc.n_pairs > 65536u ? 20u : ((MEDIUM || scatter) ? 6u : 8u);
     if (!fb_args.shadow_min_lanes) fb_args.shadow_min_lanes = sc.n_pairs > 65536u ? 12u : 1u;
     hipLaunchKernelGGL((render_kernel<MATS, MEDIUM, WAVES>), dim3(grid), dim3(PT_BLOCK), lds, stream, sc, cam, S, fb_args, fb);
 }

@@ -45,7 +45,7 @@ BVH::BVH(const std::shared_ptr<IO::ModelLoader>& ml, unsigned max_leaf_size, flo
             tb.insert(tb.end(), b, b + 6);
             for (int a = 0; a < 3; ++a) ce.push_back((b[2 * a] + b[2 * a + 1]) * 0.5f);
         }
-    if (traversal_cost_ <= 0.0f) traversal_cost_ = (tb.size() / 6 >= 65536) ? 1.5f : 1.0f;
+    if (traversal_cost_ <= 0.0f) traversal_cost_ = 1.0f;
     build(tb, ce);
 }
 

@@ -20,9 +20,9 @@ using cl_BVHnode = prt_bvh_node;
 
 class BVH {
 public:
-    // traversal_cost <= 0 picks the measured optimum: 1 for small meshes (teapot: fatter leaves are monotonically
-    // slower on MI355X), 1.5 from 64 k triangles up (871 k-triangle mesh, 4K frame: 216 / 219 / 211 / 196 / 182 Msamples/s at cost 1 / 1.5 / 2 / 2.5 / 3.5
-    // with the 5-wave kernel; with the 4-wave kernel of earlier in the round 2.5 was the optimum)
+    // traversal_cost <= 0 picks the measured optimum, 1: fatter leaves are slower on MI355X at every mesh size since the walk
+    // defers its leaves (teapot: monotonically; 871 k-triangle mesh, 4K frame, 512 spp: 4.12 / 4.10 / 4.10 / 3.98 / 3.87 G segments/s
+    // at cost 0.5 / 0.7 / 1 / 1.5 / 2 -- the round-2 kernel, which tested leaves inside the box loop, preferred 1.5)
     explicit BVH(const std::shared_ptr<IO::ModelLoader>& ml, unsigned max_leaf_size = 16, float traversal_cost = 0.0f);
     std::unique_ptr<std::vector<uint64_t>> GetPrimitiveIndices() const;
     std::unique_ptr<std::vector<cl_BVHnode>> PrepareData() const;

@@ -102,7 +102,7 @@ c = sums(["pmc_dragon%d.json" % k for k in range(1, 4)])
 dragon = {
     "workload": "cornell_dragon.json (871 k-triangle stand-in) 3840x2160, 8 spp",
     "workload_key": "3840x2160_cornell_dragon.json", "spp": 8,
-    "kernel": "render_kernel<LIGHT|DIFF, 6 waves> (lane machine with deferred leaves, walk_min_lanes 12 for both walk phases, tri_q 4)",
+    "kernel": "render_kernel<LIGHT|DIFF, 6 waves> (lane machine with deferred leaves, walk_min_lanes 20 / shadow_min_lanes 12, tri_q 4, 4096 frames per launch)",
     "counters": c,
     "derived": derived(c, segments_of("pmc_dragon1.log")),
 }

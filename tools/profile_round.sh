@@ -4,9 +4,10 @@
 set -e
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_round
-rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 cd $R
+if [ "$1" != "dragon" ]; then   # "dragon": only the big-mesh counter passes (merged over the earlier files of the round)
+rm -rf $O; mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py > $O/bench_under_rocprof.log 2>&1
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
 grep '^{' $O/bench_under_rocprof.log | tail -1 > $O/bench_under_rocprof.json
@@ -24,6 +25,8 @@ for set in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SAL
   rm -rf $O/pmc_set$i
 done
 echo done; ls $O
+fi
+mkdir -p $O
 # the 871 k-triangle stand-in at BASELINE config 5's resolution (3840x2160, one GPU, few spp): where a big tree spends its time
 j=0
 for set in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_WAVES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum"; do
