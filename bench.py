@@ -15,14 +15,15 @@ image of that frame), and ONE RCCL collective per step -- a gather of every rank
 puts the framebuffer together there, inside the timed region.  By default rank 0 then renders
 the whole frame alone (untimed) and the JSON line says whether the merged frame equals it bit for bit.
 
-Scaling.  Default "strong": the FIXED base frame (BASELINE config 2: 1920x1080, 1024 spp) split N
-ways, so the N = 1 / 2 / 4 / 8 runs measure the same job.  At 1080p that stops scaling early for a
-structural reason measured in DESIGN.md s5: the frame has 32 400 waves of pixels, eight MI355X hold
-32 768 resident waves, so the run time falls to the sequential chain of the slowest tile
-(spp x path length segments, one after the other), not to work / N.  With N = 8 the run adds
-BASELINE config 5 -- the 871 k-triangle stand-in at 3840x2160, 8-way split -- as `config5`.
-`--scaling weak` (opt-in) fixes the per-GPU work instead: the N-GPU frame has N x the pixels of the
-base frame (both dimensions x sqrt(N): 2720x1530, 3840x2160, 5424x3051).
+Scaling.  Pixels are independent units: the path shards with no data-path exchange, so the N-GPU line is a WEAK-scaling
+measurement (default): the per-GPU work is fixed -- the same view rendered with N x the pixels of the base frame (both
+dimensions x sqrt(N): 2720x1530, 3840x2160, 5424x3051 for N = 2, 4, 8; same camera, same spp, hence the same cost per
+pixel), every rank renders its interleaved row blocks, one gather per step.  N = 1 is BASELINE config 2 itself.
+The same run also reports, as `fixed_frame`, the FIXED base frame (1920x1080, 1024 spp) split N ways (strong scaling, one
+step): at 1080p that stops scaling early for a structural reason measured in DESIGN.md s5 -- the frame has 32 400 waves of
+pixels, eight MI355X hold 49 152 resident waves, so the run time falls to the sequential chain of the slowest tile
+(spp x path length segments, one after the other), not to work / N.  `--scaling strong` makes that split the headline line
+instead.  With N = 8 the run adds BASELINE config 5 -- the 871 k-triangle stand-in at 3840x2160, 8-way split -- as `config5`.
 
 The JSON line also carries
   roofline      the dominant kernel (render_kernel) priced in ALGORITHMIC bytes: 240 B per pixel
@@ -169,8 +170,10 @@ def main():
     ap.add_argument("--scene", default="cornell_diffuse.json")
     ap.add_argument("--env", default="", choices=["", "sky"], help="sky = the procedural 1024x512 HDR stand-in (configs 3, 4)")
     ap.add_argument("--phase", default="isotropic", choices=["isotropic", "hg", "rayleigh"], help="phase function of the global medium (config 4)")
-    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
-                    help="N > 1: strong (default) = the FIXED base frame split N ways; weak = N x the pixels (frame x sqrt(N) per dimension)")
+    ap.add_argument("--scaling", default="weak", choices=["strong", "weak"],
+                    help="N > 1: weak (default) = N x the pixels (frame x sqrt(N) per dimension, fixed work per GPU); strong = the FIXED base frame split N ways")
+    ap.add_argument("--no-fixed-frame", action="store_true",
+                    help="N > 1, weak scaling: skip the extra one-step run of the fixed base frame split N ways (`fixed_frame`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true",
                     help="N > 1: skip the check that rank 0's merged frame equals, bit for bit, the frame one GPU renders alone")
@@ -217,6 +220,11 @@ def main():
     verify = world > 1 and not a.no_verify
     res = run_workload(prt, par, torch, dist, np, a, world, rank, local_rank, a.scene, a.width, a.height, a.spp, a.env, a.phase,
                        a.scaling, a.steps, a.warmup, verify)
+    # beside the weak-scaling line: the fixed base frame split N ways (strong scaling), one step
+    res_fixed = None
+    if world > 1 and a.scaling == "weak" and not a.no_fixed_frame:
+        res_fixed = run_workload(prt, par, torch, dist, np, a, world, rank, local_rank, a.scene, a.width, a.height, a.spp, a.env, a.phase,
+                                 "strong", 1, 1, False)
     # BASELINE config 5 is defined on 8 GPUs: the 871 k-triangle stand-in at 3840x2160, 8-way tile split + framebuffer merge
     res5 = None
     if (world == 8 or (world > 1 and os.environ.get("PRT_BENCH_CONFIG5") == "1")) and a.config5_spp > 0 and a.scene == "cornell_diffuse.json":
@@ -295,6 +303,9 @@ def main():
         }
         if res["verified"] is not None:
             out["config"]["merged_frame_equals_single_gpu_render"] = res["verified"]
+        if res_fixed is not None:
+            out["fixed_frame"] = {"workload": "%s %dx%d %dspp split over %d ranks (strong scaling of the base frame, one step)" % (a.scene, a.width, a.height, a.spp, world),
+                                  "value": round(res_fixed["msamples"], 3), "unit": "Msamples/s", "ms_per_step": round(res_fixed["ms_per_step"], 3)}
         if res5 is not None:
             out["config5"] = {"workload": "scenes/cornell_dragon (871 k-triangle stand-in) 3840x2160 %dspp, %d x MI355X tile split + RCCL framebuffer merge "
                                           "(BASELINE config 5 at a reduced spp: the full 8192 spp is %d x this work)" % (res5["spp"], world, 8192 // max(res5["spp"], 1)),
