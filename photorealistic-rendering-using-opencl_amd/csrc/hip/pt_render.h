@@ -25,11 +25,11 @@ using namespace dev;
 #define PT_WAIT_RATIO 1u    // a walk phase is cut short only while more than this many lanes wait per lane still walking (0: while
                             // any lane waits -- the first form of the rule: 1.3 % slower on cornell, the same on the big mesh)
 #endif
-// waves per SIMD the register allocator must leave room for: 6 (80 VGPRs).  The history of this number is the history of the lane's
-// registers: 4 (128 VGPRs) while the SLP vectorizer paired floats into 64-bit registers; 5 (96) without it and with the
-// lane's flags as bit-fields of one word; 6 once fields of different phases shared registers, the cached hit dropped its position
-// and the walk state its spare words -- +1 ... 3 % over 5 on every variant (LIGHT|DIFF: 56 B of scratch at 80 VGPRs, none at 96;
-// generic: 88 B; with a medium 76 ... 120 B), +4 ... 7 % through a tree beyond one XCD's L2.  7 waves the same, 8: -10 %.
+// waves per SIMD the register allocator must leave room for: two builds per set, 5 (96 VGPRs) and 6 (80).  The history of these numbers
+// is the history of the lane's registers: 4 (128 VGPRs) while the SLP vectorizer paired floats into 64-bit registers; 5
+// without it and with the lane's flags as bit-fields of one word; 6 once fields of different phases shared registers, the cached hit
+// dropped its position and the walk state its spare words.  Which of the two a launch takes: launch_variant.  7 waves the same as 6
+// or worse, 8: -10 ... 20 %.
 // LaunchOpts::waves = 5 / 6 forces one build (PT_WAVES / PT_BIG_WAVES; prt_set_option "waves", PRT_WAVES).
 #ifndef PT_BIG_WAVES
 #define PT_BIG_WAVES 6
@@ -233,13 +233,15 @@ static void launch_variant_w(const DevScene& sc, const DevCamera& cam, const Dev
     if (!grid) return;
     FrameArgs fb_args = fa;
     fb_args.scatter = scatter ? 1u : 0u;
-    // walk phases end below this many walking lanes (0 = not set by the caller): 8; 6 with a medium (8: -1 %) and for scattered
-    // pixels, whose waves hold more deep walks (512x512 coat: 6 +4 %).  Shadow rays: in a small tree 99 % end at the root and the
+    // walk phases end below this many walking lanes (0 = not set by the caller): 8 in the 6-wave builds (10 / 12: +-0.5 % on box A of
+    // launch_variant, +1.5 % on box B; the SDF sets: 10 -3 %), 12 in the 5-wave builds (box B, cornell: 8 / 10 / 12 / 14 / 16 / 20 -> 11.39 /
+    // 11.52 / 11.63 / 11.59 / 11.42 / 11.04 G segments/s); 6 with a medium (8: -1 %) and for scattered pixels, whose waves hold more deep
+    // walks (512x512 coat: 6 +4 %).  Shadow rays: in a small tree 99 % end at the root and the
     // rest is shallow -- cutting one off costs its pixel a whole iteration, letting the wave finish them costs a few steps (cornell
     // +3 %); through a big mesh they are as deep as any ray and the bound pays as it does for the closest-hit walks (+14 %).
-    // Through a tree beyond one XCD's L2: 16 / 12 (3840x2160 x 512 spp, 4096 frames per launch: 12 / 12 -> 3.84, 16 / 16 -> 3.93, 16 / 12 -> 3.96 G
-    // segments/s; round 2, 512 frames per launch: 8 -> 2.46, 12 -> 2.52, 16 -> 2.51).
-    if (!fb_args.walk_min_lanes) fb_args.walk_min_lanes = sc.n_pairs > 65536u ? 20u : ((MEDIUM || scatter) ? 6u : 8u);
+    // Through a tree beyond one XCD's L2: 20 / 12 (3840x2160 x 512 spp, 4096 frames per launch: 12 / 12 -> 3.84, 16 / 16 -> 3.93, 16 / 12 -> 3.96,
+    // 20 / 12 -> 4.02 G segments/s; round 2, 512 frames per launch: 8 -> 2.46, 12 -> 2.52, 16 -> 2.51).
+    if (!fb_args.walk_min_lanes) fb_args.walk_min_lanes = sc.n_pairs > 65536u ? 20u : ((MEDIUM || scatter) ? 6u : (WAVES <= PT_WAVES ? 12u : 8u));
     if (!fb_args.shadow_min_lanes) fb_args.shadow_min_lanes = sc.n_pairs > 65536u ? 12u : 1u;
     hipLaunchKernelGGL((render_kernel<MATS, MEDIUM, WAVES>), dim3(grid), dim3(PT_BLOCK), lds, stream, sc, cam, S, fb_args, fb);
 }
@@ -249,12 +251,18 @@ static RenderLaunch launch_variant(const char* name, const DevScene& sc, const D
                                    hipStream_t stream, const LaunchOpts& lo) {
     bool scatter;
     const unsigned grid = launch_grid(sc, fa, lo, scatter);
-    // 6 waves per SIMD; 5 where a launch of a small tree is one or two rounds of waves (scattered pixels): every wave then runs at its
-    // own latency and the spills of the 80-register build cost more than the sixth wave hides (512x512 coat: 5 +5 %)
-    const int waves = lo.waves ? lo.waves : ((scatter && sc.n_pairs <= 65536u) ? PT_WAVES : PT_BIG_WAVES);
+    // Waves per SIMD = which register budget the set runs best at.  6 (80 registers) for the light sets, with a medium, for the raymarched
+    // SDF sets and through big trees; 5 (96 registers) for the sets whose 80-register build spills most -- the coat set (68 instead of 152 B
+    // of scratch) and the generic dispatch (112 instead of 208 B) -- and for scattered pixels of a small tree (one or two rounds of waves,
+    // every wave at its own latency: 512x512 coat +5 %).  Measured at 1080p on two kinds of box of the pool, 5 against 6 waves:
+    //   box A (headline 12.87 G segments/s): LIGHT|DIFF -6 %, rough conductor -3.8 %, rough dielectric -2.3 %, coat +1.3 %, generic +-0
+    //   box B (headline 11.28, same build):  LIGHT|DIFF +1 %, rough conductor +5 %,   rough dielectric +1.4 %, coat +9 %,   generic +15 %;
+    //   with a medium -4 %, SDF -8 % on B.  What a box loses at 6 waves grows with the set's scratch: B's memory system is the slower one.
+    constexpr bool five = !MEDIUM && !(MATS & PT_MATS_SDF) && ((MATS & ~PT_MATS_FLAGS) == 0u || (MATS & PRT_MAT_COAT) != 0u);
+    const int waves = lo.waves ? lo.waves : (sc.n_pairs > 65536u ? PT_BIG_WAVES : ((scatter || five) ? PT_WAVES : PT_BIG_WAVES));
     RenderLaunch r;
     r.name = name; r.scatter = scatter ? 1 : 0;
-#ifdef PT_DEV_ONE_VARIANT
+#if defined(PT_DEV_ONE_VARIANT) && !defined(PT_DEV_BOTH_WAVES)
     r.waves = PT_BIG_WAVES;
     launch_variant_w<MATS, MEDIUM, PT_BIG_WAVES>(sc, cam, S, fa, fb, stream, grid, scatter);
 #else
