@@ -275,7 +275,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(res["ms_per_step"], 3),
             "higher_is_better": True,
-            "scaling": a.scaling if world > 1 else "strong",
+            "scaling": a.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",

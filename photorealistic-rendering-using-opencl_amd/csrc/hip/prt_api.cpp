@@ -70,6 +70,13 @@ struct prt_ctx {
     // the pending triangle tests of a walk phase run once this many sixteenths of its walking lanes have one (PRT_TRI_Q; render_kernel)
     uint32_t tri_sixteenths = 4;
     uint32_t run_ahead = 1;                        // FrameArgs::run_ahead of prt_render_spp's launches (PRT_RUN_AHEAD=0: off)
+    // Which register budget (5 or 6 waves per SIMD) a scene's kernel runs best at depends on the box, not only on the material set:
+    // the same build on two kinds of box of one pool disagrees by 6 ... 15 % either way (pt_render.h, launch_variant).  So
+    // prt_render_spp measures it where it can: the second launch of each sub-part of the first long render of a scene runs the
+    // other build, and the choice is kept while scene and frame stay (`tuned_waves`; 0 = not decided).  Results do not depend on it.
+    int autotune = 1;                              // PRT_AUTOTUNE=0 / option "autotune": off
+    int tuned_waves = 0;
+    bool launch_log = false;                       // PRT_LAUNCH_LOG=1: one line per retired launch on stderr
     prt_stats stats{};
     std::string err;
     LaunchOpts lo{};                               // forced wave-count build / pixel mapping / generic material set (prt_set_option)
@@ -138,6 +145,8 @@ extern "C" int prt_create(int device, const prt_config* cfg, prt_ctx** out) {
     if (const char* ev = std::getenv("PRT_SCATTER")) { const int k = std::atoi(ev); if (k == 0 || k == 1) c->lo.scatter = k; }
     if (const char* ev = std::getenv("PRT_GENERIC")) c->lo.generic = std::atoi(ev) != 0 ? 1 : 0;
     if (const char* ev = std::getenv("PRT_TRI_Q")) { const int k = std::atoi(ev); if (k >= 0 && k <= 16) c->tri_sixteenths = (uint32_t)k; }
+    if (const char* ev = std::getenv("PRT_AUTOTUNE")) c->autotune = std::atoi(ev) != 0 ? 1 : 0;
+    if (const char* ev = std::getenv("PRT_LAUNCH_LOG")) c->launch_log = std::atoi(ev) != 0;
     if (const char* ev = std::getenv("PRT_SHADOW_MIN_LANES")) { const int k = std::atoi(ev); if (k >= 1 && k <= 64) c->shadow_min_lanes = (uint32_t)k; }
     *out = c;
     return PRT_OK;
@@ -229,6 +238,7 @@ extern "C" int prt_upload_scene(prt_ctx* c, const prt_scene_desc* s) {
         if (rc) return rc;
     }
     c->have_scene = true;
+    c->tuned_waves = 0;
     return PRT_OK;
 }
 
@@ -307,6 +317,7 @@ static int alloc_frame(prt_ctx* c, int width, int full_height, int row0, int row
     }
     c->width = width; c->full_height = full_height; c->row0 = row0; c->rows = rows;
     c->npix = npix;
+    c->tuned_waves = 0;
     c->have_size = true;
     return prt_reset(c);
 }
@@ -381,6 +392,13 @@ static int join_streams(prt_ctx* c, int K) {
     return PRT_OK;
 }
 
+// the caller's launch options with the measured wave-count build filled in where the caller left the choice open
+static LaunchOpts tuned_opts(const prt_ctx* c) {
+    LaunchOpts lo = c->lo;
+    if (!lo.waves && c->autotune && c->tuned_waves) lo.waves = c->tuned_waves;
+    return lo;
+}
+
 extern "C" int prt_render_frames(prt_ctx* c, uint32_t first_frame, uint32_t n_frames, const int32_t* seed_pairs) {
     CTX_CHECK(c);
     int rc = ready(c, "prt_render_frames");
@@ -400,7 +418,7 @@ extern "C" int prt_render_frames(prt_ctx* c, uint32_t first_frame, uint32_t n_fr
         for (int j = 0; j < K; ++j) {
             FrameArgs fa = frame_args(c, first_frame + f, n, c->d_seeds + 2 * (size_t)f, 0, false);
             fa.tile_first = (uint32_t)j; fa.tile_stride = (uint32_t)K;
-            c->last = launch_render(c->sc, c->cam, c->S, fa, c->fb, K > 1 ? c->sub_stream[j] : c->stream, c->lo);
+            c->last = launch_render(c->sc, c->cam, c->S, fa, c->fb, K > 1 ? c->sub_stream[j] : c->stream, tuned_opts(c));
             ++c->stats.launches;
         }
     }
@@ -432,7 +450,7 @@ extern "C" int prt_render_spp(prt_ctx* c, uint32_t spp, uint32_t max_frames, con
             HIPCHK(c, hipMemsetAsync(c->d_counters, 0, sizeof(unsigned long long), c->stream));
             FrameArgs fa = frame_args(c, 1 + f, n, c->d_seeds + 2 * (size_t)f, spp, true);
             fa.seed_frames = max_frames - f; fa.run_ahead = c->run_ahead;
-            c->last = launch_render(c->sc, c->cam, c->S, fa, c->fb, c->stream, c->lo);
+            c->last = launch_render(c->sc, c->cam, c->S, fa, c->fb, c->stream, tuned_opts(c));
             ++c->stats.launches;
             f += n;
             HIPCHK(c, hipMemcpyAsync(&unfinished, c->d_counters, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
@@ -468,6 +486,14 @@ extern "C" int prt_render_spp(prt_ctx* c, uint32_t spp, uint32_t max_frames, con
         // launches queued per sub-part: 1 (the other sub-part's kernel covers the host round trip; 2 measured the same)
         static const unsigned depth = [] { const char* e = std::getenv("PRT_QUEUE_DEPTH"); return (e && std::atoi(e) == 2) ? 2u : 1u; }();
         const unsigned n_tiles = render_tile_count(c->width, c->rows);
+        // wave-count tuning (see prt_ctx::autotune): launches 2 ... 6 of every sub-part run the default build, the other one, the default, the
+        // other, the default (the first two launches of a render are not the steady state: cold start, every pixel in step; the work per
+        // launch drifts as pixels run ahead, and alternating cancels a linear drift)
+        constexpr unsigned T0 = 2u, TN = 5u;
+        bool tuning = c->autotune && !c->lo.waves && !c->tuned_waves && K == 2 && c->sc.n_pairs <= 65536u && n_tiles >= 2u;
+        int t_default = 0;
+        float t_ms[prt_ctx::MAX_SUB][TN] = {};
+        uint32_t t_n[prt_ctx::MAX_SUB][TN] = {};
         for (int j = 0; j < K; ++j) stop[j] = (unsigned)j >= n_tiles;      // a sub-part without tiles has nothing to do
         for (;;) {
             bool progressed = false, busy = false;
@@ -482,7 +508,14 @@ extern "C" int prt_render_spp(prt_ctx* c, uint32_t spp, uint32_t max_frames, con
                     fa.tile_first = (uint32_t)j; fa.tile_stride = (uint32_t)K;
                     c->h_unfinished[2 * j + slot] = ~0ull;
                     SUBCHK(hipEventRecord(c->sub_ev0[j][slot], c->sub_stream[j]));
-                    c->last = launch_render(c->sc, c->cam, c->S, fa, c->fb, c->sub_stream[j], c->lo);
+                    LaunchOpts lo = tuned_opts(c);
+                    if (tuning && t_default && issued[j] >= T0 && issued[j] < T0 + TN) lo.waves = ((issued[j] - T0) & 1u) ? 11 - t_default : t_default;
+                    c->last = launch_render(c->sc, c->cam, c->S, fa, c->fb, c->sub_stream[j], lo);
+                    if (tuning && issued[j] == 0u) {
+                        if (c->last.scatter || (t_default && t_default != c->last.waves)) tuning = false;     // (scattered pixels run one build only)
+                        else t_default = c->last.waves;
+                    }
+                    if (tuning && issued[j] >= T0 && issued[j] < T0 + TN) t_n[j][issued[j] - T0] = n;
                     SUBCHK(hipEventRecord(c->sub_ev[j][slot], c->sub_stream[j]));
                     ++c->stats.launches;
                     fj[j] += n;
@@ -499,7 +532,27 @@ extern "C" int prt_render_spp(prt_ctx* c, uint32_t spp, uint32_t max_frames, con
                     float ms = 0.f;
                     if (hipEventElapsedTime(&ms, c->sub_ev0[j][slot], c->sub_ev[j][slot]) == hipSuccess) c->stats.kernel_sum_ms += ms;
                     const unsigned long long left = __atomic_load_n(c->h_unfinished + 2 * j + slot, __ATOMIC_ACQUIRE);
-                    if (left == ~0ull) return abort_streams(PRT_ERR_HIP, "prt_render_spp: a launch ended without reporting its unfinished pixels");
+                    if (c->launch_log) std::fprintf(stderr, "prt launch: part %d #%u %.3f ms, %llu pixels unfinished%s\n", j, retired[j], ms, left, (tuning && retired[j] >= T0 && retired[j] < T0 + TN) ? " (tuning)" : "");
+                    if (tuning && retired[j] >= T0 && retired[j] < T0 + TN) {
+                        t_ms[j][retired[j] - T0] = ms;
+                        bool all = true;
+                        for (int k = 0; k < K; ++k) all = all && retired[k] + (k == j ? 1u : 0u) >= T0 + TN;
+                        if (all) {
+                            // the other build wins if its launches took at least 1.5 % less than the default's around them
+                            double other = 0.0, def = 0.0;
+                            bool valid = true;
+                            for (int k = 0; k < K; ++k)
+                                for (unsigned i = 0; i < TN; ++i) {
+                                    valid = valid && t_n[k][i] == step && t_ms[k][i] > 0.f;
+                                    if (i & 1u) other += (double)t_ms[k][i] / (double)(TN / 2u); else def += (double)t_ms[k][i] / (double)(TN - TN / 2u);
+                                }
+                            if (valid) {
+                                c->tuned_waves = other < 0.985 * def ? 11 - t_default : t_default;
+                                if (c->launch_log) std::fprintf(stderr, "prt autotune: %d waves %.3f ms, %d waves %.3f ms per launch -> %d\n", t_default, def / K, 11 - t_default, other / K, c->tuned_waves);
+                            }
+                            tuning = false;
+                        }
+                    }
                     ++retired[j];
                     progressed = true;
                     if (!stop[j]) {
@@ -551,6 +604,7 @@ extern "C" int prt_set_option(prt_ctx* c, const char* name, int value) {
     else if (n == "tri_q") { if (value < 0 || value > 16) return bad(); c->tri_sixteenths = (uint32_t)value; }
     else if (n == "frames_per_launch") { if (value < 0) return bad(); c->frames_per_launch = (unsigned)value; }
     else if (n == "run_ahead") { if (value < 0 || value > 1) return bad(); c->run_ahead = (uint32_t)value; }
+    else if (n == "autotune") { if (value < 0 || value > 1) return bad(); c->autotune = value; c->tuned_waves = 0; }
     else return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_set_option: unknown option " + n);
     return PRT_OK;
 }
