@@ -6,7 +6,8 @@ for l in sys.stdin:
     if l.startswith('{'):
         j=json.loads(l); print('$1', 'Msamples/s', j['value'], 'Gseg/s', j['roofline']['gsegments_per_s'], j['roofline']['kernel'])
 "; grep "autotune" gpurun_out/tune_err.log | head -3; grep -c tuning gpurun_out/tune_err.log; }
-for a in "" "--scene cornell_roughcond.json --env sky" "--scene cornell_roughdiel.json --env sky" "--scene cornell_coat.json" "--scene cornell_media.json --env sky"; do
+if [ "$1" = "short" ]; then set -- "" "--scene cornell_roughcond.json --env sky"; else set -- "" "--scene cornell_roughcond.json --env sky" "--scene cornell_roughdiel.json --env sky" "--scene cornell_coat.json" "--scene cornell_media.json --env sky"; fi
+for a in "$@"; do
 echo "== $a"
 run "PRT_LAUNCH_LOG=1" "$a"
 run "PRT_AUTOTUNE=0 PRT_WAVES=6" "$a"
