@@ -49,6 +49,7 @@ struct prt_ctx {
     // independent (pixels are), so while one set's launch drains on its slowest tiles the other fills the CUs.
     static constexpr int MAX_SUB = 4;
     int n_sub = 2;
+    bool n_sub_forced = false;      // PRT_STREAMS given: sub_parts does not fall back to one launch for small frames
     hipStream_t sub_stream[MAX_SUB] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t sub_ev[MAX_SUB][2] = {};           // end of a sub-part's launch (two in flight per sub-part)
     hipEvent_t sub_ev0[MAX_SUB][2] = {};          // its start (prt_render_spp times every launch)
@@ -128,7 +129,7 @@ extern "C" int prt_create(int device, const prt_config* cfg, prt_ctx** out) {
         prt_destroy(c);
         return PRT_ERR_HIP;
     }
-    if (const char* ev = std::getenv("PRT_STREAMS")) { const int k = std::atoi(ev); if (k >= 1 && k <= prt_ctx::MAX_SUB) c->n_sub = k; }
+    if (const char* ev = std::getenv("PRT_STREAMS")) { const int k = std::atoi(ev); if (k >= 1 && k <= prt_ctx::MAX_SUB) { c->n_sub = k; c->n_sub_forced = true; } }
     for (int j = 0; j < c->n_sub && c->n_sub > 1; ++j)
         if ((e = hipStreamCreateWithFlags(&c->sub_stream[j], hipStreamNonBlocking)) != hipSuccess ||
             (e = hipEventCreate(&c->sub_ev[j][0])) != hipSuccess || (e = hipEventCreate(&c->sub_ev0[j][0])) != hipSuccess ||
@@ -376,7 +377,14 @@ static FrameArgs frame_args(prt_ctx* c, uint32_t first_frame, uint32_t n, const 
 }
 
 // sub-parts the megakernel renders this frame part in (1 = one launch covers every tile)
-static int sub_parts(const prt_ctx* c) { return (c->n_sub > 1 && c->sub_stream[0]) ? c->n_sub : 1; }
+// Sets of tiles rendered side by side on internal streams: 2 (PRT_STREAMS) -- but ONE launch for a frame whose waves all fit on the chip
+// at once (up to 5 120 tiles = one round at 5 waves per SIMD): two half-size launches share the chip unevenly there and the render
+// lasts as long as the slower one (512x512: 19 ... 22 ms beside 21 ... 25 ms; one launch +5 ... 8 %; 640x640 and up: two are better or equal)
+static int sub_parts(const prt_ctx* c) {
+    if (!(c->n_sub > 1 && c->sub_stream[0])) return 1;
+    if (!c->n_sub_forced && render_tile_count(c->width, c->rows) <= 5120u) return 1;
+    return c->n_sub;
+}
 // the internal streams start behind everything already queued on the caller's stream ...
 static int fork_streams(prt_ctx* c, int K) {
     HIPCHK(c, hipEventRecord(c->fork_ev, c->stream));
