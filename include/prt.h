@@ -197,9 +197,8 @@ int prt_set_walk_min_lanes(prt_ctx* ctx, uint32_t lanes);
  *                               lanes have one pending (default 4)
  *   "frames_per_launch" >= 0    frames one launch of the render kernel covers (0 = default: 512, or 4096 through a tree of more than 64 k node pairs)
  *   "run_ahead"         0 | 1   prt_render_spp: see there
- *   "autotune"          1 | 0   prt_render_spp measures, on the first long render of a scene, which of the two wave-count builds this
- *                               device runs it faster with (launches 2 ... 6 of each internal stream alternate between them) and keeps
- *                               the choice while scene and frame size stay; 0: the built-in choice.  Off while "waves" is forced. */
+ *   "tile_order"        1 | 0   prt_render_spp starts the tiles whose waves ran longest in a sub-part's first launch first in its later
+ *                               launches (and renders, until scene, camera or frame change); 0: in index order */
 int prt_set_option(prt_ctx* ctx, const char* name, int value);
 /* what the last launch ran, as text: "render_kernel<LIGHT|DIFF> waves=6 pixels=tiles" ("" before the first launch) */
 const char* prt_kernel_variant(prt_ctx* ctx);

@@ -11,6 +11,7 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <algorithm>
 
 #include "prt.h"
 #include "pt_launch.h"
@@ -71,12 +72,14 @@ struct prt_ctx {
     // the pending triangle tests of a walk phase run once this many sixteenths of its walking lanes have one (PRT_TRI_Q; render_kernel)
     uint32_t tri_sixteenths = 4;
     uint32_t run_ahead = 1;                        // FrameArgs::run_ahead of prt_render_spp's launches (PRT_RUN_AHEAD=0: off)
-    // Which register budget (5 or 6 waves per SIMD) a scene's kernel runs best at depends on the box, not only on the material set:
-    // the same build on two kinds of box of one pool disagrees by 6 ... 15 % either way (pt_render.h, launch_variant).  So
-    // prt_render_spp measures it where it can: the second launch of each sub-part of the first long render of a scene runs the
-    // other build, and the choice is kept while scene and frame stay (`tuned_waves`; 0 = not decided).  Results do not depend on it.
-    int autotune = 1;                              // PRT_AUTOTUNE=0 / option "autotune": off
-    int tuned_waves = 0;
+    // Expensive tiles first (prt_render_spp, FrameArgs::tile_order): the waves of launch 0 of each sub-part leave their run time per tile,
+    // the host sorts, and from launch 1 on -- and in later renders, until scene, camera or frame change -- the sub-part's workgroups take
+    // their tiles in that order.  A launch ends with its last tile; started last, an expensive one keeps the launch open alone.
+    int tile_sort = 1;                             // PRT_TILE_ORDER=0 / option "tile_order": off
+    uint32_t* d_tile_order[MAX_SUB] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t* d_tile_cost[MAX_SUB] = {nullptr, nullptr, nullptr, nullptr};
+    bool have_order[MAX_SUB] = {false, false, false, false};
+    std::vector<uint32_t> h_tile_cost, h_tile_order;
     bool launch_log = false;                       // PRT_LAUNCH_LOG=1: one line per retired launch on stderr
     prt_stats stats{};
     std::string err;
@@ -146,7 +149,7 @@ extern "C" int prt_create(int device, const prt_config* cfg, prt_ctx** out) {
     if (const char* ev = std::getenv("PRT_SCATTER")) { const int k = std::atoi(ev); if (k == 0 || k == 1) c->lo.scatter = k; }
     if (const char* ev = std::getenv("PRT_GENERIC")) c->lo.generic = std::atoi(ev) != 0 ? 1 : 0;
     if (const char* ev = std::getenv("PRT_TRI_Q")) { const int k = std::atoi(ev); if (k >= 0 && k <= 16) c->tri_sixteenths = (uint32_t)k; }
-    if (const char* ev = std::getenv("PRT_AUTOTUNE")) c->autotune = std::atoi(ev) != 0 ? 1 : 0;
+    if (const char* ev = std::getenv("PRT_TILE_ORDER")) c->tile_sort = std::atoi(ev) != 0 ? 1 : 0;
     if (const char* ev = std::getenv("PRT_LAUNCH_LOG")) c->launch_log = std::atoi(ev) != 0;
     if (const char* ev = std::getenv("PRT_SHADOW_MIN_LANES")) { const int k = std::atoi(ev); if (k >= 1 && k <= 64) c->shadow_min_lanes = (uint32_t)k; }
     *out = c;
@@ -161,6 +164,11 @@ static void free_frame(prt_ctx* c) {
     p = c->S.q3; free_dev(p); c->S.q3 = nullptr;
     p = c->S.q4; free_dev(p); c->S.q4 = nullptr;
     p = c->fb; free_dev(p); c->fb = nullptr;
+    for (int j = 0; j < prt_ctx::MAX_SUB; ++j) {
+        p = c->d_tile_order[j]; free_dev(p); c->d_tile_order[j] = nullptr;
+        p = c->d_tile_cost[j]; free_dev(p); c->d_tile_cost[j] = nullptr;
+        c->have_order[j] = false;
+    }
 }
 static void free_scene(prt_ctx* c) {
     free_dev(c->d_pairs); free_dev(c->d_tri_geom); free_dev(c->d_tri_nrm);
@@ -239,7 +247,7 @@ extern "C" int prt_upload_scene(prt_ctx* c, const prt_scene_desc* s) {
         if (rc) return rc;
     }
     c->have_scene = true;
-    c->tuned_waves = 0;
+    for (int j = 0; j < prt_ctx::MAX_SUB; ++j) c->have_order[j] = false;
     return PRT_OK;
 }
 
@@ -248,6 +256,7 @@ extern "C" int prt_set_camera(prt_ctx* c, const prt_camera* cam) {
     if (!cam) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_set_camera: null camera");
     make_dev_camera(*cam, c->cam);
     c->have_cam = true;
+    for (int j = 0; j < prt_ctx::MAX_SUB; ++j) c->have_order[j] = false;      // (tile costs are the view's)
     return PRT_OK;
 }
 
@@ -310,6 +319,11 @@ static int alloc_frame(prt_ctx* c, int width, int full_height, int row0, int row
     void** planes[6] = {reinterpret_cast<void**>(&c->S.q0), reinterpret_cast<void**>(&c->S.q1), reinterpret_cast<void**>(&c->S.q2),
                         reinterpret_cast<void**>(&c->S.q3), reinterpret_cast<void**>(&c->S.q4), reinterpret_cast<void**>(&c->fb)};
     for (int k = 0; k < 6 && e == hipSuccess; ++k) e = hipMalloc(planes[k], npix * 16);
+    const size_t n_tiles_alloc = (size_t)render_tile_count(width, rows);
+    for (int j = 0; j < c->n_sub && c->n_sub > 1 && e == hipSuccess; ++j) {
+        e = hipMalloc(reinterpret_cast<void**>(&c->d_tile_order[j]), n_tiles_alloc * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_tile_cost[j]), n_tiles_alloc * sizeof(uint32_t));
+    }
     if (e != hipSuccess) {
         free_frame(c);
         (void)hipGetLastError();
@@ -318,7 +332,6 @@ static int alloc_frame(prt_ctx* c, int width, int full_height, int row0, int row
     }
     c->width = width; c->full_height = full_height; c->row0 = row0; c->rows = rows;
     c->npix = npix;
-    c->tuned_waves = 0;
     c->have_size = true;
     return prt_reset(c);
 }
@@ -368,6 +381,7 @@ static FrameArgs frame_args(prt_ctx* c, uint32_t first_frame, uint32_t n, const 
     fa.unfinished = count ? c->d_counters : nullptr;
     fa.unfinished_host = nullptr;
     fa.tile_first = 0; fa.tile_stride = 1; fa.scatter = 0;
+    fa.tile_order = nullptr; fa.tile_cost = nullptr;
     // 0 = by launch (pt_kernels.hip launch_variant_w: the scattered-pixel launches and the medium variants 6, the others 8; shadow
     // phases in lock step in small trees, bounded like the closest-hit phases in big ones)
     fa.walk_min_lanes = c->walk_min_lanes;
@@ -400,13 +414,6 @@ static int join_streams(prt_ctx* c, int K) {
     return PRT_OK;
 }
 
-// the caller's launch options with the measured wave-count build filled in where the caller left the choice open
-static LaunchOpts tuned_opts(const prt_ctx* c) {
-    LaunchOpts lo = c->lo;
-    if (!lo.waves && c->autotune && c->tuned_waves) lo.waves = c->tuned_waves;
-    return lo;
-}
-
 extern "C" int prt_render_frames(prt_ctx* c, uint32_t first_frame, uint32_t n_frames, const int32_t* seed_pairs) {
     CTX_CHECK(c);
     int rc = ready(c, "prt_render_frames");
@@ -426,7 +433,7 @@ extern "C" int prt_render_frames(prt_ctx* c, uint32_t first_frame, uint32_t n_fr
         for (int j = 0; j < K; ++j) {
             FrameArgs fa = frame_args(c, first_frame + f, n, c->d_seeds + 2 * (size_t)f, 0, false);
             fa.tile_first = (uint32_t)j; fa.tile_stride = (uint32_t)K;
-            c->last = launch_render(c->sc, c->cam, c->S, fa, c->fb, K > 1 ? c->sub_stream[j] : c->stream, tuned_opts(c));
+            c->last = launch_render(c->sc, c->cam, c->S, fa, c->fb, K > 1 ? c->sub_stream[j] : c->stream, c->lo);
             ++c->stats.launches;
         }
     }
@@ -458,7 +465,7 @@ extern "C" int prt_render_spp(prt_ctx* c, uint32_t spp, uint32_t max_frames, con
             HIPCHK(c, hipMemsetAsync(c->d_counters, 0, sizeof(unsigned long long), c->stream));
             FrameArgs fa = frame_args(c, 1 + f, n, c->d_seeds + 2 * (size_t)f, spp, true);
             fa.seed_frames = max_frames - f; fa.run_ahead = c->run_ahead;
-            c->last = launch_render(c->sc, c->cam, c->S, fa, c->fb, c->stream, tuned_opts(c));
+            c->last = launch_render(c->sc, c->cam, c->S, fa, c->fb, c->stream, c->lo);
             ++c->stats.launches;
             f += n;
             HIPCHK(c, hipMemcpyAsync(&unfinished, c->d_counters, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
@@ -494,14 +501,6 @@ extern "C" int prt_render_spp(prt_ctx* c, uint32_t spp, uint32_t max_frames, con
         // launches queued per sub-part: 1 (the other sub-part's kernel covers the host round trip; 2 measured the same)
         static const unsigned depth = [] { const char* e = std::getenv("PRT_QUEUE_DEPTH"); return (e && std::atoi(e) == 2) ? 2u : 1u; }();
         const unsigned n_tiles = render_tile_count(c->width, c->rows);
-        // wave-count tuning (see prt_ctx::autotune): launches 2 ... 6 of every sub-part run the default build, the other one, the default, the
-        // other, the default (the first two launches of a render are not the steady state: cold start, every pixel in step; the work per
-        // launch drifts as pixels run ahead, and alternating cancels a linear drift)
-        constexpr unsigned T0 = 2u, TN = 5u;
-        bool tuning = c->autotune && !c->lo.waves && !c->tuned_waves && K == 2 && c->sc.n_pairs <= 65536u && n_tiles >= 2u;
-        int t_default = 0;
-        float t_ms[prt_ctx::MAX_SUB][TN] = {};
-        uint32_t t_n[prt_ctx::MAX_SUB][TN] = {};
         for (int j = 0; j < K; ++j) stop[j] = (unsigned)j >= n_tiles;      // a sub-part without tiles has nothing to do
         for (;;) {
             bool progressed = false, busy = false;
@@ -514,16 +513,13 @@ extern "C" int prt_render_spp(prt_ctx* c, uint32_t spp, uint32_t max_frames, con
                     fa.unfinished = c->d_counters + 4 + 2 * j;
                     fa.unfinished_host = c->h_unfinished + 2 * j + slot;
                     fa.tile_first = (uint32_t)j; fa.tile_stride = (uint32_t)K;
+                    if (c->tile_sort && c->d_tile_cost[j]) {
+                        fa.tile_order = c->have_order[j] ? c->d_tile_order[j] : nullptr;
+                        fa.tile_cost = (!c->have_order[j] && issued[j] == 0u) ? c->d_tile_cost[j] : nullptr;
+                    }
                     c->h_unfinished[2 * j + slot] = ~0ull;
                     SUBCHK(hipEventRecord(c->sub_ev0[j][slot], c->sub_stream[j]));
-                    LaunchOpts lo = tuned_opts(c);
-                    if (tuning && t_default && issued[j] >= T0 && issued[j] < T0 + TN) lo.waves = ((issued[j] - T0) & 1u) ? 11 - t_default : t_default;
-                    c->last = launch_render(c->sc, c->cam, c->S, fa, c->fb, c->sub_stream[j], lo);
-                    if (tuning && issued[j] == 0u) {
-                        if (c->last.scatter || (t_default && t_default != c->last.waves)) tuning = false;     // (scattered pixels run one build only)
-                        else t_default = c->last.waves;
-                    }
-                    if (tuning && issued[j] >= T0 && issued[j] < T0 + TN) t_n[j][issued[j] - T0] = n;
+                    c->last = launch_render(c->sc, c->cam, c->S, fa, c->fb, c->sub_stream[j], c->lo);
                     SUBCHK(hipEventRecord(c->sub_ev[j][slot], c->sub_stream[j]));
                     ++c->stats.launches;
                     fj[j] += n;
@@ -540,26 +536,19 @@ extern "C" int prt_render_spp(prt_ctx* c, uint32_t spp, uint32_t max_frames, con
                     float ms = 0.f;
                     if (hipEventElapsedTime(&ms, c->sub_ev0[j][slot], c->sub_ev[j][slot]) == hipSuccess) c->stats.kernel_sum_ms += ms;
                     const unsigned long long left = __atomic_load_n(c->h_unfinished + 2 * j + slot, __ATOMIC_ACQUIRE);
-                    if (c->launch_log) std::fprintf(stderr, "prt launch: part %d #%u %.3f ms, %llu pixels unfinished%s\n", j, retired[j], ms, left, (tuning && retired[j] >= T0 && retired[j] < T0 + TN) ? " (tuning)" : "");
-                    if (tuning && retired[j] >= T0 && retired[j] < T0 + TN) {
-                        t_ms[j][retired[j] - T0] = ms;
-                        bool all = true;
-                        for (int k = 0; k < K; ++k) all = all && retired[k] + (k == j ? 1u : 0u) >= T0 + TN;
-                        if (all) {
-                            // the other build wins if its launches took at least 1.5 % less than the default's around them
-                            double other = 0.0, def = 0.0;
-                            bool valid = true;
-                            for (int k = 0; k < K; ++k)
-                                for (unsigned i = 0; i < TN; ++i) {
-                                    valid = valid && t_n[k][i] == step && t_ms[k][i] > 0.f;
-                                    if (i & 1u) other += (double)t_ms[k][i] / (double)(TN / 2u); else def += (double)t_ms[k][i] / (double)(TN - TN / 2u);
-                                }
-                            if (valid) {
-                                c->tuned_waves = other < 0.985 * def ? 11 - t_default : t_default;
-                                if (c->launch_log) std::fprintf(stderr, "prt autotune: %d waves %.3f ms, %d waves %.3f ms per launch -> %d\n", t_default, def / K, 11 - t_default, other / K, c->tuned_waves);
-                            }
-                            tuning = false;
-                        }
+                    if (c->launch_log) std::fprintf(stderr, "prt launch: part %d #%u %.3f ms, %llu pixels unfinished\n", j, retired[j], ms, left);
+                    if (c->tile_sort && c->d_tile_cost[j] && !c->have_order[j] && retired[j] == 0u && !c->last.scatter && n_tiles > (unsigned)j) {
+                        // launch 0 of this sub-part is over and its stream idle: its tiles by run time, longest first, for every launch from here on
+                        const unsigned grid = (n_tiles - (unsigned)j + (unsigned)K - 1u) / (unsigned)K;
+                        c->h_tile_cost.resize(grid); c->h_tile_order.resize(grid);
+                        SUBCHK(hipMemcpyAsync(c->h_tile_cost.data(), c->d_tile_cost[j], grid * sizeof(uint32_t), hipMemcpyDeviceToHost, c->sub_stream[j]));
+                        SUBCHK(hipStreamSynchronize(c->sub_stream[j]));
+                        for (unsigned k = 0; k < grid; ++k) c->h_tile_order[k] = k;
+                        const uint32_t* cost = c->h_tile_cost.data();
+                        std::stable_sort(c->h_tile_order.begin(), c->h_tile_order.end(), [cost](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+                        SUBCHK(hipMemcpyAsync(c->d_tile_order[j], c->h_tile_order.data(), grid * sizeof(uint32_t), hipMemcpyHostToDevice, c->sub_stream[j]));
+                        SUBCHK(hipStreamSynchronize(c->sub_stream[j]));      // (the host vector is reused by the other sub-part)
+                        c->have_order[j] = true;
                     }
                     ++retired[j];
                     progressed = true;
@@ -612,7 +601,7 @@ extern "C" int prt_set_option(prt_ctx* c, const char* name, int value) {
     else if (n == "tri_q") { if (value < 0 || value > 16) return bad(); c->tri_sixteenths = (uint32_t)value; }
     else if (n == "frames_per_launch") { if (value < 0) return bad(); c->frames_per_launch = (unsigned)value; }
     else if (n == "run_ahead") { if (value < 0 || value > 1) return bad(); c->run_ahead = (uint32_t)value; }
-    else if (n == "autotune") { if (value < 0 || value > 1) return bad(); c->autotune = value; c->tuned_waves = 0; }
+    else if (n == "tile_order") { if (value < 0 || value > 1) return bad(); c->tile_sort = value; for (int j = 0; j < prt_ctx::MAX_SUB; ++j) c->have_order[j] = false; }
     else return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_set_option: unknown option " + n);
     return PRT_OK;
 }

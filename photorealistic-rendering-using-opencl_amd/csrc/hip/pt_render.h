@@ -67,7 +67,10 @@ __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene 
     // fa.scatter: the wave's 64 pixels come from 64 tiles spread over the launch's share of the frame instead of one 8x8 tile.
     // Every wave then gets its share of the expensive regions: a launch with few rounds of waves no longer waits for the
     // tiles over the mesh (512x512: +39 %); a big frame loses the coherence of neighbouring pixels' first segments (-17 %).
-    const unsigned vpix = fa.scatter ? (unsigned)lane * gridDim.x + blockIdx.x : blockIdx.x * 64u + (unsigned)lane;
+    // (not scattered: one tile per wave, and which one is the launcher's choice -- FrameArgs::tile_order)
+    const unsigned tile_k = (!fa.scatter && fa.tile_order) ? fa.tile_order[blockIdx.x] : blockIdx.x;
+    if (!fa.scatter && fa.tile_cost && lane == 0) *reinterpret_cast<volatile uint32_t*>(fa.tile_cost + tile_k) = (uint32_t)__builtin_readcyclecounter();   // start; the end turns it into a duration
+    const unsigned vpix = fa.scatter ? (unsigned)lane * gridDim.x + blockIdx.x : tile_k * 64u + (unsigned)lane;
     const unsigned tile = (vpix >> 6) * fa.tile_stride + fa.tile_first;
     const int tl = (int)(vpix & 63u);
     const int tile_x = (int)(tile % (unsigned)tiles_x), tile_y = (int)(tile / (unsigned)tiles_x);
@@ -190,6 +193,8 @@ __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene 
         const float ns = (MATS & PT_MATS_VIEW) ? 1.0f : (float)L.samples;      // write_imagef, main.cl:159 (a debug view: :161)
         fb[id] = make_float4(L.acc[0] / ns, L.acc[1] / ns, L.acc[2] / ns, L.acc[3] / ns);
     }
+    if (!fa.scatter && fa.tile_cost && lane == 0)              // (read back through memory: no register holds the start for the life of the wave)
+        fa.tile_cost[tile_k] = (uint32_t)__builtin_readcyclecounter() - *reinterpret_cast<const volatile uint32_t*>(fa.tile_cost + tile_k);
     if (fa.unfinished) {
         const bool unfinished = in_frame && !(fa.spp_limit && L.reset && L.samples >= fa.spp_limit);
         const unsigned long long m = __ballot(unfinished);

@@ -553,46 +553,32 @@ def test_environment_importance_sampling_converges_to_the_lookup_render(prt, ora
     rb.close()
 
 
-def test_wave_count_tuner_is_invisible_at_full_size(prt, oracle, monkeypatch, capfd):
-    """prt_render_spp measures which register budget of the kernel this box runs the scene best at: launches 2 ... 6 of each sub-part
-    alternate between the two builds and the faster one is kept while scene and frame stay.  BASELINE config 2's frame, 96 spp in
-    launches of 64 frames (so the render is long enough to be tuned): the tuned render, a second render of the tuned context and a render
-    with the tuner off are the same bits; the tuner reports its decision and the context keeps it until the scene changes."""
-    W, H, spp = 1920, 1080, 96
+def test_expensive_tiles_first_is_invisible_at_full_size(prt, oracle, monkeypatch):
+    """prt_render_spp sorts a sub-part's tiles by the run time their waves reported in its first launch and starts the expensive ones
+    first from then on (FrameArgs::tile_order; kept until scene, camera or frame change).  BASELINE config 2's frame, 48 spp in launches of
+    64 frames: with the order (measured in the first render, reused in the second) and without it the state and the image are the same bits."""
+    W, H, spp = 1920, 1080, 48
     monkeypatch.setenv("PRT_FRAMES_PER_LAUNCH", "64")
-    monkeypatch.setenv("PRT_LAUNCH_LOG", "1")
     seeds = prt.seed_pairs(spp * 16 + 64)
     scene, cfg, cam, env, r = _setup(prt, "cornell_diffuse", W, H)
-    r.render_spp(spp, seeds)
-    s0, i0 = r.read_state(), r.read_framebuffer()
-    log = capfd.readouterr().err
-    assert "prt autotune:" in log, log[-400:]
-    chosen = int(log.split("prt autotune:")[1].split("->")[1].split()[0])
-    assert chosen in (5, 6) and ("waves=%d" % chosen) in r.kernel_variant()
-    r.reset()
-    r.render_spp(spp, seeds)                                     # tuned: no second measurement
-    s1, i1 = r.read_state(), r.read_framebuffer()
-    assert "prt autotune:" not in capfd.readouterr().err and ("waves=%d" % chosen) in r.kernel_variant()
-    _assert_same(oracle, s0, i0, s1, i1, "tuning render vs tuned render")
-    r.upload_scene(scene)                                        # a new scene is measured again
-    r.reset()
-    r.render_spp(spp, seeds)
-    assert "prt autotune:" in capfd.readouterr().err
-    r.set_option("autotune", 0)
-    r.set_option("waves", 11 - chosen)
-    r.reset()
-    r.render_spp(spp, seeds)
-    s2, i2 = r.read_state(), r.read_framebuffer()
-    assert ("waves=%d" % (11 - chosen)) in r.kernel_variant() and "prt autotune:" not in capfd.readouterr().err
-    _assert_same(oracle, s0, i0, s2, i2, "tuned render vs the other build, tuner off")
+    out = []
+    for order in (1, 1, 0):
+        r.set_option("tile_order", order)
+        r.reset()
+        r.render_spp(spp, seeds)
+        c = r.counts(spp)
+        out.append((r.read_state(), r.read_framebuffer(), c.segments, c.samples, c.finished_pixels))
     r.close()
+    for k in (1, 2):
+        _assert_same(oracle, out[0][0], out[0][1], out[k][0], out[k][1], "tile order: render %d vs the first" % k)
+        assert out[k][2:] == out[0][2:] and out[k][4] == W * H
 
 
 def test_options_are_validated(prt):
     scene = prt.HostScene("cornell_diffuse.json")
     r = prt.Renderer(scene.config(), device=0)
     assert r.kernel_variant() == ""
-    for name, value in (("waves", 4), ("waves", 7), ("scatter", 2), ("generic", 2), ("tri_q", 17), ("frames_per_launch", -1), ("autotune", 2), ("no_such_option", 1)):
+    for name, value in (("waves", 4), ("waves", 7), ("scatter", 2), ("generic", 2), ("tri_q", 17), ("frames_per_launch", -1), ("tile_order", 2), ("no_such_option", 1)):
         with pytest.raises(prt.PrtError):
             r.set_option(name, value)
     r.close()
