@@ -260,9 +260,11 @@ static RenderLaunch launch_variant(const char* name, const DevScene& sc, const D
     // SDF sets and through big trees; 5 (96 registers) for the sets whose 80-register build spills most -- the coat set (68 instead of 152 B
     // of scratch) and the generic dispatch (112 instead of 208 B) -- and for scattered pixels of a small tree (one or two rounds of waves,
     // every wave at its own latency: 512x512 coat +5 %).  Measured at 1080p on two kinds of box of the pool, 5 against 6 waves:
-    //   box A (headline 12.87 G segments/s): LIGHT|DIFF -6 %, rough conductor -3.8 %, rough dielectric -2.3 %, coat +1.3 %, generic +-0
-    //   box B (headline 11.28, same build):  LIGHT|DIFF +1 %, rough conductor +5 %,   rough dielectric +1.4 %, coat +9 %,   generic +15 %;
-    //   with a medium -4 %, SDF -8 % on B.  What a box loses at 6 waves grows with the set's scratch: B's memory system is the slower one.
+    //   box A (headline 12.87 G segments/s): LIGHT|DIFF -6 %, rough conductor -3.6 %, rough dielectric -2.3 %, coat +1.3 %, generic +-0
+    //   box B (headline 11.28, same build):  LIGHT|DIFF +1 %, rough conductor +5 %,   rough dielectric +1.4 %, coat +9 %,   generic +15 %
+    //   box C (headline 11.43):              LIGHT|DIFF -7 %, rough conductor +10 %,  rough dielectric +-0,    coat +12 %,  generic +12 %
+    //   with a medium -4 %, SDF -8 % on B.  Same clocks and power under load on all three (DESIGN.md s4 "Two kinds of box"); A is the
+    //   healthy state -- every config is fastest there -- and decides; a set runs 5 waves where that costs nothing on A.
     constexpr bool five = !MEDIUM && !(MATS & PT_MATS_SDF) && ((MATS & ~PT_MATS_FLAGS) == 0u || (MATS & PRT_MAT_COAT) != 0u);
     const int waves = lo.waves ? lo.waves : (sc.n_pairs > 65536u ? PT_BIG_WAVES : ((scatter || five) ? PT_WAVES : PT_BIG_WAVES));
     RenderLaunch r;
