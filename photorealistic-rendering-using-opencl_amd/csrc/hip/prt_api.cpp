@@ -72,7 +72,8 @@ struct prt_ctx {
     // the pending triangle tests of a walk phase run once this many sixteenths of its walking lanes have one (PRT_TRI_Q; render_kernel)
     uint32_t tri_sixteenths = 4;
     uint32_t run_ahead = 1;                        // FrameArgs::run_ahead of prt_render_spp's launches (PRT_RUN_AHEAD=0: off)
-    // Expensive tiles first (prt_render_spp, FrameArgs::tile_order): the waves of launch 0 of each sub-part leave their run time per tile,
+    // Expensive tiles first (prt_render_spp through trees of more than 64 k node pairs, FrameArgs::tile_order): the waves of launch 0 of
+    // each sub-part leave what their tile cost (iterations),
     // the host sorts, and from launch 1 on -- and in later renders, until scene, camera or frame change -- the sub-part's workgroups take
     // their tiles in that order.  A launch ends with its last tile; started last, an expensive one keeps the launch open alone.
     int tile_sort = 1;                             // PRT_TILE_ORDER=0 / option "tile_order": off
@@ -513,7 +514,7 @@ extern "C" int prt_render_spp(prt_ctx* c, uint32_t spp, uint32_t max_frames, con
                     fa.unfinished = c->d_counters + 4 + 2 * j;
                     fa.unfinished_host = c->h_unfinished + 2 * j + slot;
                     fa.tile_first = (uint32_t)j; fa.tile_stride = (uint32_t)K;
-                    if (c->tile_sort && c->d_tile_cost[j]) {
+                    if (c->tile_sort && c->d_tile_cost[j] && c->sc.n_pairs > 65536u) {
                         fa.tile_order = c->have_order[j] ? c->d_tile_order[j] : nullptr;
                         fa.tile_cost = (!c->have_order[j] && issued[j] == 0u) ? c->d_tile_cost[j] : nullptr;
                     }
@@ -537,7 +538,7 @@ extern "C" int prt_render_spp(prt_ctx* c, uint32_t spp, uint32_t max_frames, con
                     if (hipEventElapsedTime(&ms, c->sub_ev0[j][slot], c->sub_ev[j][slot]) == hipSuccess) c->stats.kernel_sum_ms += ms;
                     const unsigned long long left = __atomic_load_n(c->h_unfinished + 2 * j + slot, __ATOMIC_ACQUIRE);
                     if (c->launch_log) std::fprintf(stderr, "prt launch: part %d #%u %.3f ms, %llu pixels unfinished\n", j, retired[j], ms, left);
-                    if (c->tile_sort && c->d_tile_cost[j] && !c->have_order[j] && retired[j] == 0u && !c->last.scatter && n_tiles > (unsigned)j) {
+                    if (c->tile_sort && c->d_tile_cost[j] && c->sc.n_pairs > 65536u && !c->have_order[j] && retired[j] == 0u && !c->last.scatter && n_tiles > (unsigned)j) {
                         // launch 0 of this sub-part is over and its stream idle: its tiles by run time, longest first, for every launch from here on
                         const unsigned grid = (n_tiles - (unsigned)j + (unsigned)K - 1u) / (unsigned)K;
                         c->h_tile_cost.resize(grid); c->h_tile_order.resize(grid);

@@ -144,7 +144,7 @@ struct FrameArgs {
     uint32_t tile_first, tile_stride;       // this launch covers the tiles tile_first + k * tile_stride (sub-part of the frame)
     const uint32_t* tile_order;             // null, or a permutation of the launch's k: workgroup g renders tile k = tile_order[g] (the expensive
                                             // tiles first: the hardware starts workgroups in index order, and a launch ends with its last tile)
-    uint32_t* tile_cost;                    // null, or where the wave of tile k leaves the shader-clock ticks it ran for (tile_cost[k])
+    uint32_t* tile_cost;                    // null, or where the wave of tile k leaves the iterations it took (tile_cost[k]): what the tile costs
     uint32_t scatter;                       // set by the launcher: lane l of wave g renders pixel l of tile (l * waves + g) / 64 ...
     uint32_t walk_min_lanes;                // lane machine: a closest-hit walk phase of a wave ends once fewer lanes than this are still walking
     uint32_t shadow_min_lanes;              // ... and an any-hit (shadow ray) phase below this many

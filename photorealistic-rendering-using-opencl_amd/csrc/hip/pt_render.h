@@ -59,7 +59,11 @@ __device__ unsigned long long g_phase_clocks[12];    // 0..5, 7 cycles per phase
 #define PT_CLK(k) do { } while (0)
 #endif
 
-template <unsigned MATS, bool MEDIUM, int WAVES>
+// ORDER: the build that takes its tiles in the launcher's order and reports what they cost (FrameArgs::tile_order / tile_cost).  A build
+// of its own because the three lines it adds are not free elsewhere: compiled into every kernel they cost the sets that spill most
+// 1.6 ... 3.7 % (rough conductor 10.83 -> 10.46 G segments/s, rough dielectric 7.06 -> 6.95, medium 8.74 -> 8.60; LIGHT|DIFF +-0) -- one more
+// scalar register alive through the frame loop -- while the order pays through big trees only (+3 ... 6 %).
+template <unsigned MATS, bool MEDIUM, int WAVES, bool ORDER = false>
 __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene sc, const DevCamera cam, const DevState S,
                                                                  const FrameArgs fa, float4* __restrict__ fb) {
     const int tiles_x = (fa.width + 7) / 8;
@@ -68,8 +72,12 @@ __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene 
     // Every wave then gets its share of the expensive regions: a launch with few rounds of waves no longer waits for the
     // tiles over the mesh (512x512: +39 %); a big frame loses the coherence of neighbouring pixels' first segments (-17 %).
     // (not scattered: one tile per wave, and which one is the launcher's choice -- FrameArgs::tile_order)
-    const unsigned tile_k = (!fa.scatter && fa.tile_order) ? fa.tile_order[blockIdx.x] : blockIdx.x;
-    if (!fa.scatter && fa.tile_cost && lane == 0) *reinterpret_cast<volatile uint32_t*>(fa.tile_cost + tile_k) = (uint32_t)__builtin_readcyclecounter();   // start; the end turns it into a duration
+    const unsigned tile_k = (ORDER && !fa.scatter && fa.tile_order) ? fa.tile_order[blockIdx.x] : blockIdx.x;
+    // What a tile costs is reported as the wave's ITERATIONS, not its clock ticks: a time stamp taken here (`s_memtime`, as intrinsic or as
+    // inline assembly) counts for the compiler as something every later load may depend on, and such a load cannot go through the scalar
+    // cache -- the quads, spheres, materials and the root of the tree all came through the vector-memory path in the first build of this
+    // (2.2 x its instructions, 6 % of the scalar loads left; found with the instruction counters, the clock said +-0).
+    unsigned iterations = 0u;
     const unsigned vpix = fa.scatter ? (unsigned)lane * gridDim.x + blockIdx.x : tile_k * 64u + (unsigned)lane;
     const unsigned tile = (vpix >> 6) * fa.tile_stride + fa.tile_first;
     const int tl = (int)(vpix & 63u);
@@ -110,6 +118,7 @@ __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene 
     for (;;) {
         const bool runnable = lane_runnable(fa, L, __any(lane_owes_frames(fa, L)));
         if (!__any(runnable || L.stage != ST_READY)) break;     // every lane has done its frames (or is frozen)
+        if (ORDER) ++iterations;
         PT_CLK(7);
 #ifdef PT_PHASE_CLOCKS
         done_lanes_ += (unsigned long long)__popcll(__ballot(!runnable && L.stage == ST_READY));
@@ -193,8 +202,7 @@ __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene 
         const float ns = (MATS & PT_MATS_VIEW) ? 1.0f : (float)L.samples;      // write_imagef, main.cl:159 (a debug view: :161)
         fb[id] = make_float4(L.acc[0] / ns, L.acc[1] / ns, L.acc[2] / ns, L.acc[3] / ns);
     }
-    if (!fa.scatter && fa.tile_cost && lane == 0)              // (read back through memory: no register holds the start for the life of the wave)
-        fa.tile_cost[tile_k] = (uint32_t)__builtin_readcyclecounter() - *reinterpret_cast<const volatile uint32_t*>(fa.tile_cost + tile_k);
+    if (ORDER && !fa.scatter && fa.tile_cost && lane == 0) fa.tile_cost[tile_k] = iterations;
     if (fa.unfinished) {
         const bool unfinished = in_frame && !(fa.spp_limit && L.reset && L.samples >= fa.spp_limit);
         const unsigned long long m = __ballot(unfinished);
@@ -233,6 +241,7 @@ static void launch_variant_w(const DevScene& sc, const DevCamera& cam, const Dev
     static size_t lds_attr = 0;                                  // per template instance
     if (lds > 65536u && lds > lds_attr) {   // only a tree that fills the reference's 64-entry stack to the brim
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<MATS, MEDIUM, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (WAVES == PT_BIG_WAVES) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<MATS, MEDIUM, WAVES, WAVES == PT_BIG_WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         lds_attr = lds;
     }
     if (!grid) return;
@@ -248,7 +257,10 @@ static void launch_variant_w(const DevScene& sc, const DevCamera& cam, const Dev
     // 20 / 12 -> 4.02 G segments/s; round 2, 512 frames per launch: 8 -> 2.46, 12 -> 2.52, 16 -> 2.51).
     if (!fb_args.walk_min_lanes) fb_args.walk_min_lanes = sc.n_pairs > 65536u ? 20u : ((MEDIUM || scatter) ? 6u : (WAVES <= PT_WAVES ? 12u : 8u));
     if (!fb_args.shadow_min_lanes) fb_args.shadow_min_lanes = sc.n_pairs > 65536u ? 12u : 1u;
-    hipLaunchKernelGGL((render_kernel<MATS, MEDIUM, WAVES>), dim3(grid), dim3(PT_BLOCK), lds, stream, sc, cam, S, fb_args, fb);
+    if (WAVES == PT_BIG_WAVES && (fb_args.tile_order || fb_args.tile_cost))     // (prt_render_spp asks for it through big trees only)
+        hipLaunchKernelGGL((render_kernel<MATS, MEDIUM, WAVES, WAVES == PT_BIG_WAVES>), dim3(grid), dim3(PT_BLOCK), lds, stream, sc, cam, S, fb_args, fb);
+    else
+        hipLaunchKernelGGL((render_kernel<MATS, MEDIUM, WAVES>), dim3(grid), dim3(PT_BLOCK), lds, stream, sc, cam, S, fb_args, fb);
 }
 // one material set x medium: picks the wave-count build and the pixel-to-wave mapping; reports both (RenderLaunch)
 template <unsigned MATS, bool MEDIUM>
@@ -262,9 +274,8 @@ static RenderLaunch launch_variant(const char* name, const DevScene& sc, const D
     // every wave at its own latency: 512x512 coat +5 %).  Measured at 1080p on two kinds of box of the pool, 5 against 6 waves:
     //   box A (headline 12.87 G segments/s): LIGHT|DIFF -6 %, rough conductor -3.6 %, rough dielectric -2.3 %, coat +1.3 %, generic +-0
     //   box B (headline 11.28, same build):  LIGHT|DIFF +1 %, rough conductor +5 %,   rough dielectric +1.4 %, coat +9 %,   generic +15 %
-    //   box C (headline 11.43):              LIGHT|DIFF -7 %, rough conductor +10 %,  rough dielectric +-0,    coat +12 %,  generic +12 %
-    //   with a medium -4 %, SDF -8 % on B.  Same clocks and power under load on all three (DESIGN.md s4 "Two kinds of box"); A is the
-    //   healthy state -- every config is fastest there -- and decides; a set runs 5 waves where that costs nothing on A.
+    //   with a medium -4 %, SDF -8 % on B.  Same clocks and power under load on both (DESIGN.md s4 "Two kinds of box"); A is the healthy
+    //   state -- every config is fastest there -- and decides; a set runs 5 waves where that costs nothing on A.
     constexpr bool five = !MEDIUM && !(MATS & PT_MATS_SDF) && ((MATS & ~PT_MATS_FLAGS) == 0u || (MATS & PRT_MAT_COAT) != 0u);
     const int waves = lo.waves ? lo.waves : (sc.n_pairs > 65536u ? PT_BIG_WAVES : ((scatter || five) ? PT_WAVES : PT_BIG_WAVES));
     RenderLaunch r;
