@@ -200,7 +200,8 @@ int prt_set_walk_min_lanes(prt_ctx* ctx, uint32_t lanes);
  *   "tile_order"        1 | 0   prt_render_spp starts the tiles whose waves ran longest in a sub-part's first launch first in its later
  *                               launches (and renders, until scene, camera or frame change); 0: in index order */
 int prt_set_option(prt_ctx* ctx, const char* name, int value);
-/* what the last launch ran, as text: "render_kernel<LIGHT|DIFF> waves=6 pixels=tiles" ("" before the first launch) */
+/* what the last launch ran, as text: "render_kernel<LIGHT|DIFF> waves=6 pixels=tiles" ("" before the first launch; "pixels=scattered",
+ * "pixels=tiles, expensive first": see prt_set_option) */
 const char* prt_kernel_variant(prt_ctx* ctx);
 
 int prt_synchronize(prt_ctx* ctx);

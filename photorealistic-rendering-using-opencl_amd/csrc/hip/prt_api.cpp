@@ -609,7 +609,7 @@ extern "C" int prt_set_option(prt_ctx* c, const char* name, int value) {
 
 extern "C" const char* prt_kernel_variant(prt_ctx* c) {
     if (!c) return "";
-    c->variant = std::string(c->last.name) + (c->last.waves ? " waves=" + std::to_string(c->last.waves) + (c->last.scatter ? " pixels=scattered" : " pixels=tiles") : "");
+    c->variant = std::string(c->last.name) + (c->last.waves ? " waves=" + std::to_string(c->last.waves) + (c->last.scatter ? " pixels=scattered" : (c->last.ordered ? " pixels=tiles, expensive first" : " pixels=tiles")) : "");
     return c->variant.c_str();
 }
 

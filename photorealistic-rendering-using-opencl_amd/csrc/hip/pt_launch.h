@@ -14,7 +14,7 @@ struct LaunchOpts {
     int generic = 0;        // 1: the run-time-dispatched material set even where the scene's own set is compiled
 };
 // what a launch ran: kernel variant, wave-count build, pixel-to-wave mapping (prt_kernel_variant)
-struct RenderLaunch { const char* name = ""; int waves = 0; int scatter = 0; };
+struct RenderLaunch { const char* name = ""; int waves = 0; int scatter = 0; int ordered = 0; };   // ordered: the tiles were taken in the launcher's order
 
 // launches the scene-specialised variant (the AOT analogue of the reference's per-scene program
 // build, include/CL/cl_kernel.h:226-345)

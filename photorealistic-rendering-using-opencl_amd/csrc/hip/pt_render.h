@@ -280,6 +280,7 @@ static RenderLaunch launch_variant(const char* name, const DevScene& sc, const D
     const int waves = lo.waves ? lo.waves : (sc.n_pairs > 65536u ? PT_BIG_WAVES : ((scatter || five) ? PT_WAVES : PT_BIG_WAVES));
     RenderLaunch r;
     r.name = name; r.scatter = scatter ? 1 : 0;
+    r.ordered = (!scatter && fa.tile_order && waves >= PT_BIG_WAVES) ? 1 : 0;
 #if defined(PT_DEV_ONE_VARIANT) && !defined(PT_DEV_BOTH_WAVES)
     r.waves = PT_BIG_WAVES;
     launch_variant_w<MATS, MEDIUM, PT_BIG_WAVES>(sc, cam, S, fa, fb, stream, grid, scatter);

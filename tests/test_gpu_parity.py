@@ -553,19 +553,26 @@ def test_environment_importance_sampling_converges_to_the_lookup_render(prt, ora
     rb.close()
 
 
-def test_expensive_tiles_first_is_invisible_at_full_size(prt, oracle, monkeypatch):
-    """prt_render_spp sorts a sub-part's tiles by the run time their waves reported in its first launch and starts the expensive ones
-    first from then on (FrameArgs::tile_order; kept until scene, camera or frame change).  BASELINE config 2's frame, 48 spp in launches of
-    64 frames: with the order (measured in the first render, reused in the second) and without it the state and the image are the same bits."""
-    W, H, spp = 1920, 1080, 48
-    monkeypatch.setenv("PRT_FRAMES_PER_LAUNCH", "64")
+def test_expensive_tiles_first_is_invisible(prt, oracle, monkeypatch):
+    """Through a big tree prt_render_spp sorts a sub-part's tiles by what their waves reported in its first launch (iterations) and starts
+    the expensive ones first from then on (FrameArgs::tile_order, the ORDER build of the kernel; kept until scene, camera or frame
+    change).  The 871 k-triangle stand-in at 2560x1440 (the smallest 16:9 frame whose sub-parts are not scattered), 3 spp in launches of 8
+    frames: with the order (measured in the first render, reused in the second) and without it the state and the image are the same bits."""
+    W, H, spp = 2560, 1440, 3
+    monkeypatch.setenv("PRT_FRAMES_PER_LAUNCH", "8")
+    prt.ensure_dragon_standin()
     seeds = prt.seed_pairs(spp * 16 + 64)
-    scene, cfg, cam, env, r = _setup(prt, "cornell_diffuse", W, H)
+    scene = prt.HostScene("cornell_dragon.json")
+    r = prt.Renderer(scene.config(), device=0)
+    r.upload_scene(scene)
+    r.set_camera(prt.default_camera(W, H))
+    r.resize(W, H)
     out = []
     for order in (1, 1, 0):
         r.set_option("tile_order", order)
         r.reset()
         r.render_spp(spp, seeds)
+        assert ("expensive first" in r.kernel_variant()) == bool(order), r.kernel_variant()
         c = r.counts(spp)
         out.append((r.read_state(), r.read_framebuffer(), c.segments, c.samples, c.finished_pixels))
     r.close()
