@@ -392,12 +392,16 @@ static FrameArgs frame_args(prt_ctx* c, uint32_t first_frame, uint32_t n, const 
 }
 
 // sub-parts the megakernel renders this frame part in (1 = one launch covers every tile)
-// Sets of tiles rendered side by side on internal streams: 2 (PRT_STREAMS) -- but ONE launch for a frame whose waves all fit on the chip
-// at once (up to 5 120 tiles = one round at 5 waves per SIMD): two half-size launches share the chip unevenly there and the render
-// lasts as long as the slower one (512x512: 19 ... 22 ms beside 21 ... 25 ms; one launch +5 ... 8 %; 640x640 and up: two are better or equal)
-static int sub_parts(const prt_ctx* c) {
+// Sets of tiles rendered side by side on internal streams: 2 (PRT_STREAMS) -- but ONE launch for a SHORT render of a frame whose waves all
+// fit on the chip at once (up to 5 120 tiles = one round at 5 waves per SIMD; `frames` = the frames the render is expected to take, at
+// most two launches' worth): two half-size launches share the chip unevenly there and the render lasts as long as the slower one (512x512 x
+// 64 spp: 19 ... 22 ms beside 21 ... 25 ms; one launch +5 ... 8 %, also at 128 spp; 640x640 and up: two are better or equal).  A LONG render
+// of such a frame -- one rank's share of a 1080p frame at 1 024 spp, 16 launches -- wants the two sets: each covers the ends of the
+// other's launches (0.375 s against 0.426 s).
+static int sub_parts(const prt_ctx* c, unsigned long long frames) {
     if (!(c->n_sub > 1 && c->sub_stream[0])) return 1;
-    if (!c->n_sub_forced && render_tile_count(c->width, c->rows) <= 5120u) return 1;
+    const unsigned step = c->frames_per_launch ? c->frames_per_launch : (c->sc.n_pairs > 65536u ? 4096u : 512u);
+    if (!c->n_sub_forced && render_tile_count(c->width, c->rows) <= 5120u && frames <= 2ull * step) return 1;
     return c->n_sub;
 }
 // the internal streams start behind everything already queued on the caller's stream ...
@@ -425,7 +429,7 @@ extern "C" int prt_render_frames(prt_ctx* c, uint32_t first_frame, uint32_t n_fr
     if (!n_frames) return PRT_OK;
     if ((rc = ensure_seeds(c, seed_pairs, n_frames))) return rc;
     const unsigned step = c->frames_per_launch ? c->frames_per_launch : (c->sc.n_pairs > 65536u ? 4096u : 512u);
-    const int K = sub_parts(c);
+    const int K = sub_parts(c, n_frames);
     c->stats.concurrent = (uint32_t)K;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     if (K > 1 && (rc = fork_streams(c, K))) return rc;
@@ -455,7 +459,7 @@ extern "C" int prt_render_spp(prt_ctx* c, uint32_t spp, uint32_t max_frames, con
     c->stats.launches = 0; c->stats.frames = 0; c->stats.kernel_ms = 0.0; c->stats.kernel_sum_ms = 0.0; c->stats.concurrent = 1;
     if ((rc = ensure_seeds(c, seed_pairs, max_frames))) return rc;
     const unsigned step = c->frames_per_launch ? c->frames_per_launch : (c->sc.n_pairs > 65536u ? 4096u : 512u);
-    const int K = sub_parts(c);
+    const int K = sub_parts(c, 8ull * spp);            // (a path takes 4.4 ... 7.2 segments on the BASELINE scenes)
     c->stats.concurrent = (uint32_t)K;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     uint32_t f = 0;
