@@ -247,10 +247,9 @@ static void launch_variant_w(const DevScene& sc, const DevCamera& cam, const Dev
     if (!grid) return;
     FrameArgs fb_args = fa;
     fb_args.scatter = scatter ? 1u : 0u;
-    // walk phases end below this many walking lanes (0 = not set by the caller): 8 in the 6-wave builds (10 / 12: +-0.5 % on box A of
-    // launch_variant, +1.5 % on box B; the SDF sets: 10 -3 %), 12 in the 5-wave builds (box B, cornell: 8 / 10 / 12 / 14 / 16 / 20 -> 11.39 /
-    // 11.52 / 11.63 / 11.59 / 11.42 / 11.04 G segments/s); 6 with a medium (8: -1 %) and for scattered pixels, whose waves hold more deep
-    // walks (512x512 coat: 6 +4 %).  Shadow rays: in a small tree 99 % end at the root and the
+    // walk phases end below this many walking lanes (0 = not set by the caller): 8 in the 6-wave builds (10 / 12: +-0.5 %; the SDF sets: 10
+    // -3 %), 12 in the 5-wave builds (+1 % over 8); 6 with a medium (8: -1 %) and for scattered pixels, whose waves hold more deep walks
+    // (512x512 coat: 6 +4 %).  Shadow rays: in a small tree 99 % end at the root and the
     // rest is shallow -- cutting one off costs its pixel a whole iteration, letting the wave finish them costs a few steps (cornell
     // +3 %); through a big mesh they are as deep as any ray and the bound pays as it does for the closest-hit walks (+14 %).
     // Through a tree beyond one XCD's L2: 20 / 12 (3840x2160 x 512 spp, 4096 frames per launch: 12 / 12 -> 3.84, 16 / 16 -> 3.93, 16 / 12 -> 3.96,
@@ -271,11 +270,8 @@ static RenderLaunch launch_variant(const char* name, const DevScene& sc, const D
     // Waves per SIMD = which register budget the set runs best at.  6 (80 registers) for the light sets, with a medium, for the raymarched
     // SDF sets and through big trees; 5 (96 registers) for the sets whose 80-register build spills most -- the coat set (68 instead of 152 B
     // of scratch) and the generic dispatch (112 instead of 208 B) -- and for scattered pixels of a small tree (one or two rounds of waves,
-    // every wave at its own latency: 512x512 coat +5 %).  Measured at 1080p on two kinds of box of the pool, 5 against 6 waves:
-    //   box A (headline 12.87 G segments/s): LIGHT|DIFF -6 %, rough conductor -3.6 %, rough dielectric -2.3 %, coat +1.3 %, generic +-0
-    //   box B (headline 11.28, same build):  LIGHT|DIFF +1 %, rough conductor +5 %,   rough dielectric +1.4 %, coat +9 %,   generic +15 %
-    //   with a medium -4 %, SDF -8 % on B.  Same clocks and power under load on both (DESIGN.md s4 "Two kinds of box"); A is the healthy
-    //   state -- every config is fastest there -- and decides; a set runs 5 waves where that costs nothing on A.
+    // every wave at its own latency: 512x512 coat +5 %).  Measured at 1080p, 5 against 6 waves: LIGHT|DIFF -6 %, rough conductor -3.6 %,
+    // rough dielectric -2.3 %, coat +1.3 %, generic +-0; with a medium -4 ... -7 %, SDF -8 %.
     constexpr bool five = !MEDIUM && !(MATS & PT_MATS_SDF) && ((MATS & ~PT_MATS_FLAGS) == 0u || (MATS & PRT_MAT_COAT) != 0u);
     const int waves = lo.waves ? lo.waves : (sc.n_pairs > 65536u ? PT_BIG_WAVES : ((scatter || five) ? PT_WAVES : PT_BIG_WAVES));
     RenderLaunch r;
