@@ -247,14 +247,13 @@ static void launch_variant_w(const DevScene& sc, const DevCamera& cam, const Dev
     if (!grid) return;
     FrameArgs fb_args = fa;
     fb_args.scatter = scatter ? 1u : 0u;
-    // walk phases end below this many walking lanes (0 = not set by the caller): 8 in the 6-wave builds (10 / 12: +-0.5 %; the SDF sets: 10
-    // -3 %), 12 in the 5-wave builds (+1 % over 8); 6 with a medium (8: -1 %) and for scattered pixels, whose waves hold more deep walks
-    // (512x512 coat: 6 +4 %).  Shadow rays: in a small tree 99 % end at the root and the
+    // walk phases end below this many walking lanes (0 = not set by the caller): 8 (10 / 12: +-0.7 % in either wave-count build; the SDF
+    // sets: 10 -3 %); 6 with a medium (8: -1 %) and for scattered pixels, whose waves hold more deep walks (512x512 coat: 6 +4 %).  Shadow rays: in a small tree 99 % end at the root and the
     // rest is shallow -- cutting one off costs its pixel a whole iteration, letting the wave finish them costs a few steps (cornell
     // +3 %); through a big mesh they are as deep as any ray and the bound pays as it does for the closest-hit walks (+14 %).
     // Through a tree beyond one XCD's L2: 20 / 12 (3840x2160 x 512 spp, 4096 frames per launch: 12 / 12 -> 3.84, 16 / 16 -> 3.93, 16 / 12 -> 3.96,
     // 20 / 12 -> 4.02 G segments/s; round 2, 512 frames per launch: 8 -> 2.46, 12 -> 2.52, 16 -> 2.51).
-    if (!fb_args.walk_min_lanes) fb_args.walk_min_lanes = sc.n_pairs > 65536u ? 20u : ((MEDIUM || scatter) ? 6u : (WAVES <= PT_WAVES ? 12u : 8u));
+    if (!fb_args.walk_min_lanes) fb_args.walk_min_lanes = sc.n_pairs > 65536u ? 20u : ((MEDIUM || scatter) ? 6u : 8u);
     if (!fb_args.shadow_min_lanes) fb_args.shadow_min_lanes = sc.n_pairs > 65536u ? 12u : 1u;
     if (WAVES == PT_BIG_WAVES && (fb_args.tile_order || fb_args.tile_cost))     // (prt_render_spp asks for it through big trees only)
         hipLaunchKernelGGL((render_kernel<MATS, MEDIUM, WAVES, WAVES == PT_BIG_WAVES>), dim3(grid), dim3(PT_BLOCK), lds, stream, sc, cam, S, fb_args, fb);
@@ -271,7 +270,7 @@ static RenderLaunch launch_variant(const char* name, const DevScene& sc, const D
     // SDF sets and through big trees; 5 (96 registers) for the sets whose 80-register build spills most -- the coat set (68 instead of 152 B
     // of scratch) and the generic dispatch (112 instead of 208 B) -- and for scattered pixels of a small tree (one or two rounds of waves,
     // every wave at its own latency: 512x512 coat +5 %).  Measured at 1080p, 5 against 6 waves: LIGHT|DIFF -6 %, rough conductor -3.6 %,
-    // rough dielectric -2.3 %, coat +1.3 %, generic +-0; with a medium -4 ... -7 %, SDF -8 %.
+    // rough dielectric -2.3 %, coat +-0 ... +1.3 %, generic +-0; with a medium -7 %, SDF -15 %.
     constexpr bool five = !MEDIUM && !(MATS & PT_MATS_SDF) && ((MATS & ~PT_MATS_FLAGS) == 0u || (MATS & PRT_MAT_COAT) != 0u);
     const int waves = lo.waves ? lo.waves : (sc.n_pairs > 65536u ? PT_BIG_WAVES : ((scatter || five) ? PT_WAVES : PT_BIG_WAVES));
     RenderLaunch r;
