@@ -192,6 +192,9 @@ int prt_set_walk_min_lanes(prt_ctx* ctx, uint32_t lanes);
  *   "generic"           0 | 1   1: the material set dispatched at run time even where the scene's own ACTIVE_MATS is compiled (the
  *                               reference compiles exactly the scene's set, include/CL/cl_kernel.h:226-345; compiled here: LIGHT|DIFF,
  *                               +COAT, +ROUGH_COND, +DIEL|ROUGH_DIEL)
+ *   "any_dist"          0 | 1   1: the compiled set's instance that carries all three microfacet distributions even where every microfacet
+ *                               lobe of the scene uses the same one (`mat->dist` is a run-time field in the reference,
+ *                               kernels/bxdf/microfacet.cl:6-9; compiled here: GGX for the rough sets, Beckmann for the coat set)
  *   "walk_min_lanes", "shadow_min_lanes"   0 (by launch) .. 64   see prt_set_walk_min_lanes
  *   "tri_q"             0 .. 16  the triangle tests that a walk phase's box steps found run once this many sixteenths of its walking
  *                               lanes have one pending (default 4)

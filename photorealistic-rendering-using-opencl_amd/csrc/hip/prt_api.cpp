@@ -149,6 +149,7 @@ extern "C" int prt_create(int device, const prt_config* cfg, prt_ctx** out) {
     if (const char* ev = std::getenv("PRT_WAVES")) { const int k = std::atoi(ev); if (k == 5 || k == 6) c->lo.waves = k; }
     if (const char* ev = std::getenv("PRT_SCATTER")) { const int k = std::atoi(ev); if (k == 0 || k == 1) c->lo.scatter = k; }
     if (const char* ev = std::getenv("PRT_GENERIC")) c->lo.generic = std::atoi(ev) != 0 ? 1 : 0;
+    if (const char* ev = std::getenv("PRT_ANY_DIST")) c->lo.any_dist = std::atoi(ev) != 0 ? 1 : 0;
     if (const char* ev = std::getenv("PRT_TRI_Q")) { const int k = std::atoi(ev); if (k >= 0 && k <= 16) c->tri_sixteenths = (uint32_t)k; }
     if (const char* ev = std::getenv("PRT_TILE_ORDER")) c->tile_sort = std::atoi(ev) != 0 ? 1 : 0;
     if (const char* ev = std::getenv("PRT_LAUNCH_LOG")) c->launch_log = std::atoi(ev) != 0;
@@ -601,6 +602,7 @@ extern "C" int prt_set_option(prt_ctx* c, const char* name, int value) {
     if (n == "waves") { if (value != 0 && value != 5 && value != 6) return bad(); c->lo.waves = value; }
     else if (n == "scatter") { if (value < -1 || value > 1) return bad(); c->lo.scatter = value; }
     else if (n == "generic") { if (value < 0 || value > 1) return bad(); c->lo.generic = value; }
+    else if (n == "any_dist") { if (value < 0 || value > 1) return bad(); c->lo.any_dist = value; }
     else if (n == "walk_min_lanes") { if (value < 0 || value > 64) return bad(); c->walk_min_lanes = (uint32_t)value; }
     else if (n == "shadow_min_lanes") { if (value < 0 || value > 64) return bad(); c->shadow_min_lanes = (uint32_t)value; }
     else if (n == "tri_q") { if (value < 0 || value > 16) return bad(); c->tri_sixteenths = (uint32_t)value; }

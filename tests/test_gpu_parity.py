@@ -467,9 +467,9 @@ def test_wave_count_builds_match_golden(prt, oracle, variant, waves, scatter):
     assert "waves=%d" % waves in ran and ("pixels=scattered" if scatter else "pixels=tiles") in ran, ran
 
 
-COMPILED_SETS = {"cornell_diffuse": "<LIGHT|DIFF>", "cornell_media": "<LIGHT|DIFF,medium>", "cornell_coat": "<LIGHT|DIFF|COAT>",
-                 "cornell_quadlight": "<LIGHT|DIFF|COAT>", "cornell_roughcond": "<LIGHT|DIFF|ROUGH_COND>",
-                 "cornell_roughdiel": "<LIGHT|DIFF|DIEL|ROUGH_DIEL>"}
+COMPILED_SETS = {"cornell_diffuse": "<LIGHT|DIFF>", "cornell_media": "<LIGHT|DIFF,medium>", "cornell_coat": "<LIGHT|DIFF|COAT; Beckmann>",
+                 "cornell_quadlight": "<LIGHT|DIFF|COAT>", "cornell_roughcond": "<LIGHT|DIFF|ROUGH_COND; GGX>",
+                 "cornell_roughdiel": "<LIGHT|DIFF|DIEL|ROUGH_DIEL; GGX>"}
 
 
 @pytest.mark.parametrize("variant", list(VARIANTS))
@@ -480,6 +480,9 @@ def test_compiled_material_sets_and_generic_dispatch_match_golden(prt, oracle, v
     picked = _golden_through(prt, oracle, variant, "scene's own set")
     if variant in COMPILED_SETS:
         assert COMPILED_SETS[variant] in picked, picked
+        if ";" in COMPILED_SETS[variant]:                        # ... and through the set's instance with every microfacet distribution
+            wide = _golden_through(prt, oracle, variant, "set with all distributions", any_dist=1)
+            assert COMPILED_SETS[variant].split(";")[0] + ">" in wide, wide
     forced = _golden_through(prt, oracle, variant, "generic set", generic=1)
     assert "generic" in forced, forced
 
@@ -585,7 +588,7 @@ def test_options_are_validated(prt):
     scene = prt.HostScene("cornell_diffuse.json")
     r = prt.Renderer(scene.config(), device=0)
     assert r.kernel_variant() == ""
-    for name, value in (("waves", 4), ("waves", 7), ("scatter", 2), ("generic", 2), ("tri_q", 17), ("frames_per_launch", -1), ("tile_order", 2), ("no_such_option", 1)):
+    for name, value in (("waves", 4), ("waves", 7), ("scatter", 2), ("generic", 2), ("any_dist", 2), ("tri_q", 17), ("frames_per_launch", -1), ("tile_order", 2), ("no_such_option", 1)):
         with pytest.raises(prt.PrtError):
             r.set_option(name, value)
     r.close()
