@@ -325,6 +325,7 @@ static int alloc_frame(prt_ctx* c, int width, int full_height, int row0, int row
     for (int j = 0; j < c->n_sub && c->n_sub > 1 && e == hipSuccess; ++j) {
         e = hipMalloc(reinterpret_cast<void**>(&c->d_tile_order[j]), n_tiles_alloc * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_tile_cost[j]), n_tiles_alloc * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemset(c->d_tile_cost[j], 0, n_tiles_alloc * sizeof(uint32_t));    // (a forced 5-wave build reports no costs: all equal then)
     }
     if (e != hipSuccess) {
         free_frame(c);
