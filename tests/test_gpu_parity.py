@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import ALPHA_VARIANTS, variant_config, GOLDEN, PKG_NAME, VARIANTS, VIEW_VARIANTS, variant_camera
+from conftest import ALPHA_VARIANTS, variant_config, GOLDEN, PKG_NAME, ROOT, VARIANTS, VIEW_VARIANTS, variant_camera
 
 pytestmark = pytest.mark.gpu
 
@@ -986,3 +986,31 @@ def test_device_functions_match_reference_kat(prt):
     from test_kat import check_env_lookup
     check_env_lookup(r.selftest_fn)             # read_imagef semantics worked out from the OpenCL 1.2 specification
     r.close()
+
+
+def test_bench_line_keeps_the_contract(prt):
+    """`python bench.py` as the driver runs it (fewer spp): ONE JSON line with the contract's keys, the roofline and the CPU baseline"""
+    import json
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--spp", "16"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.split("\n") if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline"):
+        assert key in j, key
+    assert j["unit"] == "Msamples/s" and j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["higher_is_better"] is True
+    assert j["value"] > 0 and j["ms_per_step"] > 0 and j["vs_baseline"] is None and j["dtype"] == "f32" and j["data"] == "synthetic"
+    assert "workload" in j["config"] and "model" not in j["config"]
+    r = j["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "valu", "kernel"):
+        assert key in r, key
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert "render_kernel<LIGHT|DIFF>" in r["kernel"]
+    c = j["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in c, key
+    assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1
