@@ -84,6 +84,51 @@ PT_HD f3 cross(f3 a, f3 b) { return F3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * 
 PT_HD float length(f3 a) { return hw_sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
 PT_HD f3 normalize(f3 a) { float inv = hw_recip(hw_sqrt(a.x * a.x + a.y * a.y + a.z * a.z)); return F3(a.x * inv, a.y * inv, a.z * inv); }
 PT_HD f3 ld3(const float* p) { return F3(p[0], p[1], p[2]); }
+
+// ---- uniform scene tables: scalar loads BY CONSTRUCTION ------------------------------------------------------------------------
+// The quads, spheres, SDF primitives, the materials, the light table, the seed table and the root of the tree are read at addresses
+// that are (mostly) the same in every lane.  Through an ordinary global pointer such a load is given to the scalar unit only while the
+// compiler can prove that nothing in the kernel wrote before it -- one LDS atomic, one `asm volatile`, one time stamp in front of the
+// frame loop and every one of them silently became a vector load (11 ... 19 % slower, bit-exact; round 3).  The kernel never writes these
+// tables, so they are read through the CONSTANT address space (AMDGPU address space 4: memory that does not change while the kernel
+// runs): a load from it at a uniform address is an s_load whatever else the kernel does, at a divergent address the same global load as
+// before.  tests/test_codegen.py compiles the headline set with a deliberate clobber in front of the frame loop and counts.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PT_CONST __attribute__((address_space(4)))
+#else
+#define PT_CONST                                       // host compilations (tests/emu, the camera basis): plain memory
+#endif
+typedef float pt_vf4 __attribute__((ext_vector_type(4)));
+typedef unsigned pt_vu4 __attribute__((ext_vector_type(4)));
+template <typename T> PT_HD const PT_CONST pt_vf4* const_vf4(const T* p) { return (const PT_CONST pt_vf4*)p; }
+PT_HD unsigned const_u32(const uint32_t* p, unsigned i) { return ((const PT_CONST uint32_t*)p)[i]; }
+PT_HD int const_i32(const int32_t* p, unsigned i) { return ((const PT_CONST int32_t*)p)[i]; }
+PT_HD float const_f32(const float* p, size_t i) { return ((const PT_CONST float*)p)[i]; }
+PT_HD DevSphere const_sphere(const DevSphere* p, unsigned i) {
+    const pt_vf4 a = const_vf4(p + i)[0];
+    DevSphere s;
+    s.pos[0] = a.x; s.pos[1] = a.y; s.pos[2] = a.z; s.radius = a.w;
+    return s;
+}
+PT_HD DevQuad const_quad(const DevQuad* p, unsigned i) {
+    const PT_CONST pt_vf4* q = const_vf4(p + i);
+    const pt_vf4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4];
+    DevQuad r;
+    r.base[0] = a.x; r.base[1] = a.y; r.base[2] = a.z; r.area = a.w;
+    r.edge0[0] = b.x; r.edge0[1] = b.y; r.edge0[2] = b.z; r.e0e0 = b.w;
+    r.edge1[0] = c.x; r.edge1[1] = c.y; r.edge1[2] = c.z; r.e1e1 = c.w;
+    r.normal[0] = d.x; r.normal[1] = d.y; r.normal[2] = d.z; r.u0 = d.w;
+    r.anchor[0] = e.x; r.anchor[1] = e.y; r.anchor[2] = e.z; r.u1 = e.w;
+    return r;
+}
+PT_HD DevSdf const_sdf(const DevSdf* p, unsigned i) {
+    const PT_CONST pt_vf4* q = const_vf4(p + i);
+    const pt_vf4 a = q[0], b = q[1];
+    DevSdf r;
+    r.pos[0] = a.x; r.pos[1] = a.y; r.pos[2] = a.z; r.type = prt_f2u(a.w);
+    r.params[0] = b.x; r.params[1] = b.y; r.params[2] = b.z; r.params[3] = b.w;
+    return r;
+}
 PT_DEV f3 vexp(f3 a) { return F3(prt_exp(a.x), prt_exp(a.y), prt_exp(a.z)); }
 PT_DEV float fmax3(f3 v) { return prt_fmax(prt_fmax(v.x, v.y), v.z); }
 PT_DEV float avg3(f3 v) { return (v.x * 1.0f + v.y * 1.0f + v.z * 1.0f) * 0.3333333333333333333333333333333333333333333333f; }
@@ -140,12 +185,16 @@ struct Mat {                                                     // Material, he
 template <unsigned DM = 7u>
 PT_DEV Mat load_mat(const DevMaterial* m) {
     Mat r;
-    r.color = ld3(m->color); r.roughness = m->roughness;
-    r.eta = ld3(m->eta); r.k = ld3(m->k);
-    unsigned b = m->bits;
+    const PT_CONST pt_vf4* q = const_vf4(m);                 // (a uniform `m` -- the light's material -- is three scalar loads)
+    const pt_vf4 a = q[0], e = q[1], kk = q[2];
+    r.color = F3(a.x, a.y, a.z); r.roughness = a.w;
+    r.eta = F3(e.x, e.y, e.z); r.k = F3(kk.x, kk.y, kk.z);
+    unsigned b = prt_f2u(e.w);
     r.t = b & 0xffffu; r.lobes = (b >> 16) & 0xffu; r.dist = (b >> 24) & DM;
     return r;
 }
+
+PT_DEV unsigned mat_bits(const DevMaterial* m) { return const_u32(reinterpret_cast<const uint32_t*>(m), 7u); }   // DevMaterial::bits
 
 // ---- sampling warps, kernels/utils.cl:92-152 ------------------------------------------------
 PT_DEV f3 uniform_sphere(float xi_x, float xi_y) {
@@ -255,9 +304,9 @@ PT_DEV bool hit_triangle_data(const float4 a, const float4 b, const float4 c4, c
     return false;
 }
 PT_DEV bool hit_triangle(const TriGeom* __restrict__ tg, unsigned slot, const Ray& ray, float& best_t, TriHit& th) {
-    const float4* q = reinterpret_cast<const float4*>(tg + slot);
-    const float4 a = q[0], b = q[1], c4 = q[2];
-    return hit_triangle_data(a, b, c4, slot, ray, best_t, th);
+    const PT_CONST pt_vf4* q = const_vf4(tg + slot);                // (only the root-is-a-leaf loop comes here: a uniform slot)
+    const pt_vf4 a = q[0], b = q[1], c4 = q[2];
+    return hit_triangle_data(make_float4(a.x, a.y, a.z, a.w), make_float4(b.x, b.y, b.z, b.w), make_float4(c4.x, c4.y, c4.z, c4.w), slot, ray, best_t, th);
 }
 
 // Traversal stack in LDS, [level][thread] (conflict-free), `levels` chosen per scene from the tree
@@ -297,6 +346,15 @@ PT_DEV PairTest test_pair(const PairData& d, const RayPre& p, float best_t) {
     return r;
 }
 
+// the pair at a wave-uniform index (the root): four scalar loads, by construction (PT_CONST above)
+PT_DEV PairData load_pair_uniform(const NodePair* __restrict__ pairs, unsigned node) {
+    const PT_CONST pt_vf4* q = const_vf4(pairs + node);
+    const pt_vf4 a = q[0], b = q[1], c = q[2], m = q[3];
+    PairData d;
+    d.b0 = make_float4(a.x, a.y, a.z, a.w); d.b1 = make_float4(b.x, b.y, b.z, b.w); d.b2 = make_float4(c.x, c.y, c.z, c.w);
+    d.meta = make_uint4(prt_f2u(m.x), prt_f2u(m.y), prt_f2u(m.z), prt_f2u(m.w));
+    return d;
+}
 struct TravRes { bool found; float t; TriHit th; };
 
 #if defined(PT_WALK_STATS) && !defined(PT_EMU)    // development builds (with -DPT_PHASE_CLOCKS): wave-level counts of the walk (tools/phase_clocks.sh)
@@ -347,7 +405,7 @@ PT_DEV void walk_begin(const DevScene& sc, const bool ANY_HIT, const Ray& ray, c
     // The step at the root, which every lane of the wave takes, reads its node through the scalar cache (the address is
     // uniform): no vector-memory instruction, and the 6 rays in 10 that miss both of the root's children never issue one
     // in this walk.  A root with a leaf child that is hit takes the general step from node 0.
-    const PairData d = load_pair(sc.pairs, 0u);
+    const PairData d = load_pair_uniform(sc.pairs, 0u);
     const PairTest pt = test_pair(d, p, ANY_HIT ? tmax : w.t);
     const uint4 meta = d.meta;
     if (!((pt.go0 & (meta.y != 0xFFFFFFFFu)) | (pt.go1 & (meta.w != 0xFFFFFFFFu)))) {
@@ -489,7 +547,7 @@ PT_DEV float s_map(const DevSdf& sdf, f3 pos) {
 PT_DEV float sdf_map(const DevScene& sc, float tmin, f3 pos, int& id) {
     float dist = tmin;
     for (unsigned i = 0; i < sc.n_sdfs; ++i) {
-        const float temp_dist = s_map(sc.sdfs[i], pos);
+        const float temp_dist = s_map(const_sdf(sc.sdfs, i), pos);
         if (temp_dist < dist) { dist = temp_dist; id = (int)(sc.n_spheres + i); }
     }
     return dist;
@@ -539,7 +597,7 @@ PT_DEV bool finish_closest(const DevScene& sc, Ray& ray, const TravRes& tr, int&
     ray.pos = ray.origin + ray.dir * t;
     if (sc.geom_flags & PRT_GEOM_SPHERE) {
         for (unsigned i = 0; i < sc.n_spheres; ++i) {
-            const DevSphere s = sc.spheres[i];
+            const DevSphere s = const_sphere(sc.spheres, i);
             if (hit_sphere(s, ray, t)) {
                 ray.pos = ray.origin + ray.dir * t;
                 ray.normal = normalize(ray.pos - ld3(s.pos));
@@ -550,22 +608,23 @@ PT_DEV bool finish_closest(const DevScene& sc, Ray& ray, const TravRes& tr, int&
     if (SDF && sc.n_sdfs) {                                                                  // intersect.cl:185-194
         if (intersect_sdf(sc, ray, t, mesh_id)) {
             ray.pos = ray.origin + ray.dir * t;
-            ray.normal = sdf_normal(sc.sdfs[mesh_id - (int)sc.n_spheres], ray.pos);
+            ray.normal = sdf_normal(const_sdf(sc.sdfs, (unsigned)(mesh_id - (int)sc.n_spheres)), ray.pos);
         }
     }
     if (sc.geom_flags & PRT_GEOM_QUAD) {
         for (unsigned i = 0; i < sc.n_quads; ++i) {
             f3 q;
-            if (hit_quad(sc.quads[i], ray, t, q)) {
+            const DevQuad qd = const_quad(sc.quads, i);
+            if (hit_quad(qd, ray, t, q)) {
                 ray.backside = false;
-                ray.normal = ld3(sc.quads[i].normal);
+                ray.normal = ld3(qd.normal);
                 ray.pos = q;
                 mesh_id = (int)(sc.quad_mesh_base + i);
             }
         }
     }
     bool nTrans = true;
-    if (sc.ntrans_mask) nTrans = ((sc.mats[mesh_id + 1].bits & 0xffffu) & ~sc.ntrans_mask) != 0;
+    if (sc.ntrans_mask) nTrans = ((mat_bits(sc.mats + (mesh_id + 1)) & 0xffffu) & ~sc.ntrans_mask) != 0;
     ray.t = t;
     ray.backside = dot(ray.normal, ray.dir) > 0.0f;
     if (nTrans && ray.backside) ray.normal = -ray.normal;
@@ -580,13 +639,13 @@ PT_DEV bool finish_shadow(const DevScene& sc, const f3 origin, const f3 dir, con
     float t = maxDist;
     if (sc.geom_flags & PRT_GEOM_SPHERE) {
         for (unsigned i = 0; i < sc.n_spheres; ++i)
-            if (hit_sphere(sc.spheres[i], ray, t)) return false;     // an accepted hit always has t < maxDist
+            if (hit_sphere(const_sphere(sc.spheres, i), ray, t)) return false;     // an accepted hit always has t < maxDist
     }
     if (SDF && sc.n_sdfs && shadow_sdf(sc, origin, dir, maxDist)) return false;                     // intersect.cl:119-126
     if (sc.geom_flags & PRT_GEOM_QUAD) {
         for (unsigned i = 0; i < sc.n_quads; ++i) {
             f3 q;
-            if (hit_quad(sc.quads[i], ray, t, q)) return false;
+            if (hit_quad(const_quad(sc.quads, i), ray, t, q)) return false;
         }
     }
     return true;
@@ -639,13 +698,13 @@ PT_DEV float quad_direct_pdf(const DevQuad& qd, f3 dir, f3 p) {
 }
 // directPdf of the mesh that a probe ray hit (mesh_id >= 0)
 PT_DEV float direct_pdf_mesh(const DevScene& sc, int mesh_id, f3 dir, f3 p) {
-    if ((sc.geom_flags & PRT_GEOM_SPHERE) && (unsigned)mesh_id < sc.n_spheres) return sphere_direct_pdf(sc.spheres[mesh_id], p);
-    if ((sc.geom_flags & PRT_GEOM_QUAD) && (unsigned)mesh_id >= sc.quad_mesh_base) return quad_direct_pdf(sc.quads[mesh_id - sc.quad_mesh_base], dir, p);
+    if ((sc.geom_flags & PRT_GEOM_SPHERE) && (unsigned)mesh_id < sc.n_spheres) return sphere_direct_pdf(const_sphere(sc.spheres, (unsigned)mesh_id), p);
+    if ((sc.geom_flags & PRT_GEOM_QUAD) && (unsigned)mesh_id >= sc.quad_mesh_base) return quad_direct_pdf(const_quad(sc.quads, (unsigned)mesh_id - sc.quad_mesh_base), dir, p);
     return 0.0f;
 }
 PT_DEV bool sample_light0(const DevScene& sc, f3 p, LightSample& ls, Rng& rng) {
-    if (sc.light_sphere != 0xFFFFFFFFu) return sphere_sample_direct(sc.spheres[sc.light_sphere], p, ls, rng);
-    if (sc.light_quad != 0xFFFFFFFFu) return quad_sample_direct(sc.quads[sc.light_quad], p, ls, rng);
+    if (sc.light_sphere != 0xFFFFFFFFu) return sphere_sample_direct(const_sphere(sc.spheres, sc.light_sphere), p, ls, rng);
+    if (sc.light_quad != 0xFFFFFFFFu) return quad_sample_direct(const_quad(sc.quads, sc.light_quad), p, ls, rng);
     return false;
 }
 // the light of lightSample / volumeLightSample (base.cl:88-93,202-207) and its sample: LIGHT_INDICES[0], or -- PICK: the reference's
@@ -654,9 +713,9 @@ PT_DEV bool sample_light0(const DevScene& sc, f3 p, LightSample& ls, Rng& rng) {
 PT_DEV bool sample_light(const DevScene& sc, const bool PICK, f3 p, LightSample& ls, Rng& rng, unsigned& mesh) {
     if (!PICK) { mesh = sc.light_mesh; return sample_light0(sc, p, ls, rng); }
     const int k = (int)(next1D(rng) * (float)(sc.light_count + 1u));
-    mesh = sc.light_tab[k];
-    if ((sc.geom_flags & PRT_GEOM_SPHERE) && mesh < sc.n_spheres) return sphere_sample_direct(sc.spheres[mesh], p, ls, rng);
-    if ((sc.geom_flags & PRT_GEOM_QUAD) && mesh >= sc.quad_mesh_base) return quad_sample_direct(sc.quads[mesh - sc.quad_mesh_base], p, ls, rng);
+    mesh = const_u32(sc.light_tab, (unsigned)k);
+    if ((sc.geom_flags & PRT_GEOM_SPHERE) && mesh < sc.n_spheres) return sphere_sample_direct(const_sphere(sc.spheres, mesh), p, ls, rng);
+    if ((sc.geom_flags & PRT_GEOM_QUAD) && mesh >= sc.quad_mesh_base) return quad_sample_direct(const_quad(sc.quads, mesh - sc.quad_mesh_base), p, ls, rng);
     return false;                                    // geometry.cl:11-32: only spheres and quads can be sampled
 }
 
@@ -1391,7 +1450,7 @@ template <unsigned MATS, bool MEDIUM>
 PT_DEV void lane_front(const DevScene& sc, const DevCamera& cam, const FrameArgs& fa, Lane& L, int gx, int gy) {
     if (!L.begun) {                                                      // main.cl:108-136
         const unsigned frame = fa.first_frame + L.f;
-        const int random0 = fa.seed_pairs[2 * L.f], random1 = fa.seed_pairs[2 * L.f + 1];
+        const int random0 = const_i32(fa.seed_pairs, 2u * L.f), random1 = const_i32(fa.seed_pairs, 2u * L.f + 1u);
         L.rng.s0 = (unsigned)gx * frame % 1000u + ((unsigned)random0 * 100u);      // main.cl:108-109
         L.rng.s1 = (unsigned)gy * frame % 1000u + ((unsigned)random1 * 100u);
         { const float tt = L.t; L.t = L.time; L.time = tt; }                        // tempToRay after rayToTemp, main.cl:27-28
@@ -1539,7 +1598,7 @@ PT_DEV void lane_back(const DevScene& sc, Lane& L) {
         const Mat mat = load_mat<dist_mask<MATS>()>((L.mesh_id + 1) ? &sc.mats[L.mesh_id + 1] : &sc.mats[sc.n_meshes + 1]);
         if (L.w2_ran && L.h.didHit) {                                    // the probe ray, base.cl:58-75
             const int mid = L.h.mesh_id;
-            const unsigned lbits = sc.mats[mid + 1].bits;
+            const unsigned lbits = mat_bits(sc.mats + (mid + 1));
             if (lbits & PRT_MAT_LIGHT) {
                 const Mat lm = load_mat(&sc.mats[mid + 1]);
                 L.a = lm.color * L.weight * power_heuristic(L.pdf, direct_pdf_mesh(sc, mid, L.dir, hit_pos));
@@ -1595,7 +1654,7 @@ PT_DEV void lane_back(const DevScene& sc, Lane& L) {
         sh_o = L.origin;
         if (L.h.didHit) {
             const int mid = L.h.mesh_id;
-            const unsigned lbits = sc.mats[mid + 1].bits;
+            const unsigned lbits = mat_bits(sc.mats + (mid + 1));
             if (lbits & PRT_MAT_LIGHT) {
                 const Mat lm = load_mat(&sc.mats[mid + 1]);
                 const f3 tr = vexp(splat(sc.fog_sigma_t) * (-1.0f * L.h.t));

@@ -110,6 +110,12 @@ __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene 
     TravStack stk;
     stk.lds = lds_stack + threadIdx.x; stk.stride = PT_BLOCK;
     const unsigned T = fa.walk_min_lanes, TD = fa.shadow_min_lanes, TQ = fa.tri_sixteenths;
+#ifdef PT_TEST_CLOBBER
+    // tests/test_codegen.py: what a time stamp, an `asm volatile` or an LDS atomic in front of the frame loop is to the compiler -- a
+    // write that every later load may depend on.  The uniform loads of the kernel must stay scalar behind it (pt_device.h, PT_CONST).
+    asm volatile("" ::: "memory");
+    atomicAdd(&lds_stack[0], 1u);
+#endif
 #ifdef PT_PHASE_CLOCKS
     unsigned long long clk_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_readcyclecounter();
     const unsigned long long start_ = last_;
