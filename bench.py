@@ -192,6 +192,15 @@ def main():
         if world == 1 and a.gpus > 1:
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
         a.gpus = world
+    # what is timed is the library the working tree builds, or nothing: a libprt.so left behind by other sources (round 3: an experiment's
+    # kernel, twice) is refused before anything runs -- needs no GPU.  (A missing library is built below, from the tree.)
+    if os.path.exists(os.path.join(ROOT, PKG_NAME, "libprt.so")) or os.environ.get("PRT_LIB"):
+        pkg0 = importlib.import_module(PKG_NAME)
+        try:
+            pkg0.check_build_id()
+        except pkg0.StaleLibrary as e:
+            sys.stderr.write("bench.py: refusing to time a stale library: %s\n" % e)
+            raise SystemExit(3)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libprt has no CPU fallback")
     # rehearsal knobs for a 1-GPU box: PRT_BENCH_BACKEND=gloo + PRT_BENCH_ONE_DEVICE=1 run N ranks on cuda:0
@@ -279,6 +288,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "build_id": prt.build_id(),
             "config": {"workload": "%s %dx%d %dspp%s%s, %d x MI355X" % (
                            "scenes/cornell (teapot DIFF = Lambert + sphere area light)" if a.scene == "cornell_diffuse.json" else a.scene,
                            W, H, spp, " + procedural HDR env" if a.env else "", " HG phase" if a.phase == "hg" else "", world),

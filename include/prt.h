@@ -179,7 +179,7 @@ int prt_render_spp(prt_ctx* ctx, uint32_t spp, uint32_t max_frames, const int32_
 /* Scheduling knob of the render kernel (no counterpart in the reference; results do not depend on it, tests check
  * that): a wave ends a BVH-walk phase once fewer than `lanes` of its 64 lanes are still walking (and fewer than wait for the
  * phase to end); the lanes cut off resume in the wave's next phase.  1 = every walk runs to its end (lock step).
- * Default: 8 (6 with a global medium and for launches with scattered pixels, 16 through big trees) for the closest-hit phases
+ * Default: 8 (6 with a global medium and for launches with scattered pixels, 20 through big trees) for the closest-hit phases
  * (PRT_WALK_MIN_LANES); for the shadow rays' any-hit
  * phases 1 in small trees and 12 in big ones (PRT_SHADOW_MIN_LANES).  A call of this function sets both. */
 int prt_set_walk_min_lanes(prt_ctx* ctx, uint32_t lanes);
@@ -201,8 +201,17 @@ int prt_set_walk_min_lanes(prt_ctx* ctx, uint32_t lanes);
  *   "frames_per_launch" >= 0    frames one launch of the render kernel covers (0 = default: 512, or 4096 through a tree of more than 64 k node pairs)
  *   "run_ahead"         0 | 1   prt_render_spp: see there
  *   "tile_order"        1 | 0   prt_render_spp starts the tiles whose waves ran longest in a sub-part's first launch first in its later
- *                               launches (and renders, until scene, camera or frame change); 0: in index order */
+ *                               launches (and renders, until scene, camera or frame change; setting the option to the value it has
+ *                               keeps a measured order); 0: in index order
+ *   "test_drop_report"  0 | 1   tests only: the launches of prt_render_spp report their unfinished pixels into a spare word, so that the
+ *                               call sees a launch end without a report (PRT_ERR_HIP, state unusable until prt_reset) */
 int prt_set_option(prt_ctx* ctx, const char* name, int value);
+
+/* What this library was built from (no counterpart in the reference): a hash of the content of every source, header and compiler flag
+ * of libprt.so, compiled in by the build (photorealistic-rendering-using-opencl_amd/build.py source_build_id(); a development variant of
+ * tools/build_variant.sh reads "variant-<name>-<hash>").  bench.py prints it as `build_id` and refuses to time a library whose id is
+ * not the working tree's; tests/conftest.py asserts the same.  Needs no device and no context. */
+const char* prt_build_id(void);
 /* what the last launch ran, as text: "render_kernel<LIGHT|DIFF> waves=6 pixels=tiles" ("" before the first launch; "pixels=scattered",
  * "pixels=tiles, expensive first": see prt_set_option) */
 const char* prt_kernel_variant(prt_ctx* ctx);

@@ -23,20 +23,55 @@ SCENES_DIR = os.path.join(REPO, "scenes")
 MODELS_DIR = os.path.join(SCENES_DIR, "models")
 
 __all__ = ["ensure_dragon_standin", "HostScene", "Renderer", "default_camera", "orbit_camera", "seed_pairs", "make_sky", "load_hdr", "write_hdr", "PrtError",
-           "Camera", "Config", "SceneDesc", "Stats", "PATH_STATE_DTYPE", "SCENES_DIR", "MODELS_DIR", "build"]
+           "Camera", "Config", "SceneDesc", "Stats", "PATH_STATE_DTYPE", "SCENES_DIR", "MODELS_DIR", "build", "build_id", "source_build_id", "check_build_id", "StaleLibrary"]
 
 
 class PrtError(RuntimeError):
-    pass
+    """a prt_* call returned a negative prt_status (include/prt.h); `code` is that status"""
+    def __init__(self, msg, code=None):
+        super().__init__(msg)
+        self.code = code
 
 
-def build(verbose=False):
-    """compile libprt.so in-tree (hipcc --offload-arch=gfx950)"""
+# prt_status, include/prt.h
+PRT_OK, PRT_ERR_INVALID_ARGUMENT, PRT_ERR_NO_DEVICE, PRT_ERR_HIP, PRT_ERR_NOT_READY, PRT_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
+
+
+def _build_module():
     import importlib.util
     spec = importlib.util.spec_from_file_location("_prt_build", os.path.join(HERE, "build.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    return mod.build(verbose=verbose)
+    return mod
+
+
+def build(verbose=False):
+    """compile libprt.so in-tree (hipcc --offload-arch=gfx950)"""
+    return _build_module().build(verbose=verbose)
+
+
+def build_id():
+    """prt_build_id() of the loaded library: the hash of the sources, headers and flags it was built from"""
+    return load_library().prt_build_id().decode()
+
+
+def source_build_id():
+    """the id a library built from the working tree as it is NOW would carry (build.py source_build_id)"""
+    return _build_module().source_build_id()
+
+
+class StaleLibrary(RuntimeError):
+    pass
+
+
+def check_build_id():
+    """raises StaleLibrary unless the loaded libprt.so was built from the working tree as it is now.  A development variant named through
+    PRT_LIB (tools/build_variant.sh: "variant-<name>-<hash of its sources>") is somebody's deliberate choice and passes as what it says."""
+    have, want = build_id(), source_build_id()
+    if have != want and not (os.environ.get("PRT_LIB") and have.startswith("variant-")):
+        raise StaleLibrary("libprt.so was built from other sources than the working tree holds (library %s, tree %s): "
+                           "rebuild with `python __graft_entry__.py build`" % (have, want))
+    return have
 
 
 def ensure_dragon_standin():
@@ -166,7 +201,7 @@ class Renderer:
 
     def _chk(self, rc, what):
         if rc:
-            raise PrtError("%s failed (%d): %s" % (what, rc, self.lib.prt_last_error(self.ctx).decode()))
+            raise PrtError("%s failed (%d): %s" % (what, rc, self.lib.prt_last_error(self.ctx).decode()), rc)
 
     def upload_scene(self, scene):
         desc = scene.desc if isinstance(scene, HostScene) else scene

@@ -86,6 +86,7 @@ PRT_API = [
     ("prt_set_walk_min_lanes", C.c_int, [C.c_void_p, C.c_uint32]),
     ("prt_set_option", C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     ("prt_kernel_variant", C.c_char_p, [C.c_void_p]),
+    ("prt_build_id", C.c_char_p, []),
     ("prt_synchronize", C.c_int, [C.c_void_p]),
     ("prt_read_framebuffer", C.c_int, [C.c_void_p, C.c_void_p]),
     ("prt_tonemap_rgba8", C.c_int, [C.c_void_p, C.c_void_p]),

@@ -2,6 +2,7 @@
 """Builds libprt.so in-tree: hipcc --offload-arch=gfx950 for the kernels + C-ABI, host C++ for the
 scene/camera/OBJ/BVH model.  -ffp-contract=off everywhere: the arithmetic contract of
 include/prt_detmath.h forbids implicit fma contraction on both host and device."""
+import hashlib
 import os
 import subprocess
 import sys
@@ -19,8 +20,38 @@ COMMON = ["-std=c++17", "-O3", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "
 
 HOST_SOURCES = ["host/scene.cpp", "host/camera.cpp", "host/model_loader.cpp", "host/bvh.cpp", "host/hdr_loader.cpp", "host/host_capi.cpp"]
 # the render kernel is instantiated per compile-time material set in a file of its own (pt_inst_*.hip): they compile in parallel
-HIP_SOURCES = ["hip/prt_api.cpp", "hip/pt_pack.cpp", "hip/pt_kernels.hip"] + \
+HIP_SOURCES = ["hip/prt_api.cpp", "hip/pt_pack.cpp", "hip/pt_kernels.hip", "hip/prt_build_id.cpp"] + \
     ["hip/pt_inst_%s.hip" % k for k in ("light_diff", "coat", "rough_cond", "rough_diel", "generic", "sdf", "view", "view_sdf", "pick", "envis")]
+
+
+HIP_FLAGS = ["-fno-slp-vectorize", "-x", "hip", "--offload-arch=" + ARCH]
+
+
+def source_files(root=None):
+    """every file libprt.so is made of: the sources and headers under csrc/, include/*.h and this recipe (the flags live here)"""
+    root = root or ROOT
+    csrc = os.path.join(root, os.path.basename(HERE), "csrc")
+    files = []
+    for d, _, names in os.walk(csrc):
+        files += [os.path.join(d, f) for f in names if f.endswith((".h", ".cpp", ".hip"))]
+    files += [os.path.join(root, "include", f) for f in os.listdir(os.path.join(root, "include")) if f.endswith(".h")]
+    files.append(os.path.join(root, os.path.basename(HERE), "build.py"))
+    return sorted(files)
+
+
+def source_build_id(root=None, extra=()):
+    """what prt_build_id() of a library built from the working tree returns: a hash of the CONTENT of every source, header and flag
+    (paths relative to the repository, so the id is the same in any checkout and on the GPU box)"""
+    root = root or ROOT
+    h = hashlib.sha256()
+    for f in source_files(root):
+        h.update(os.path.relpath(f, root).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+        h.update(b"\0")
+    for x in list(COMMON[:6]) + HIP_FLAGS + list(extra):        # (the -I paths are the checkout's: not part of the id)
+        h.update(x.encode() + b"\0")
+    return h.hexdigest()[:16]
 
 
 def newer(src, obj, deps):
@@ -47,16 +78,24 @@ def build(verbose=False, extra_hip_flags=()):
     headers.append(os.path.abspath(__file__))           # the flags live here
     objs = []
     jobs = []
+    # the library says what it was built from (prt_build_id(), include/prt.h): the id is compiled into prt_build_id.cpp, which is
+    # recompiled whenever the id on record differs from the working tree's
+    build_id = source_build_id(extra=extra_hip_flags)
+    id_file = os.path.join(OBJ, "build_id.txt")
+    id_stale = (not os.path.exists(id_file)) or open(id_file).read().strip() != build_id
     for s in HOST_SOURCES + HIP_SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(OBJ, s.replace("/", "_") + ".o")
         objs.append(obj)
-        if not newer(src, obj, headers):
+        is_id = s == "hip/prt_build_id.cpp"
+        if not newer(src, obj, headers) and not (is_id and id_stale):
             continue
         if s in HIP_SOURCES:
             # -fno-slp-vectorize: left on, the SLP vectorizer turns pairs of scalar float operations of the kernels into v_pk_*_f32
             # with the register shuffling that takes -- same bits, 4 % slower
-            cmd = [HIPCC] + COMMON + ["-fno-slp-vectorize", "-x", "hip", "--offload-arch=" + ARCH] + list(extra_hip_flags)
+            cmd = [HIPCC] + COMMON + HIP_FLAGS + list(extra_hip_flags)
+            if is_id:
+                cmd.append('-DPRT_BUILD_ID="%s"' % build_id)
         else:
             cmd = [HOSTCXX] + COMMON
         jobs.append(cmd + ["-c", src, "-o", obj])
@@ -69,6 +108,8 @@ def build(verbose=False, extra_hip_flags=()):
     lib = os.path.join(HERE, "libprt.so")
     if (not os.path.exists(lib)) or any(os.path.getmtime(o) > os.path.getmtime(lib) for o in objs):
         run([HIPCC, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", lib] + objs)
+    with open(id_file, "w") as fh:
+        fh.write(build_id + "\n")
     exe = os.path.join(HERE, "prt_render")
     src = os.path.join(CSRC, "host", "prt_render.cpp")
     if newer(src, exe, headers + [lib]):

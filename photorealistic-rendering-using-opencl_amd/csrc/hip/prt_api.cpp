@@ -82,10 +82,12 @@ struct prt_ctx {
     bool have_order[MAX_SUB] = {false, false, false, false};
     std::vector<uint32_t> h_tile_cost, h_tile_order;
     bool launch_log = false;                       // PRT_LAUNCH_LOG=1: one line per retired launch on stderr
+    bool test_drop_report = false;                 // option "test_drop_report" (tests only): the launches of prt_render_spp report into a spare word
     prt_stats stats{};
     std::string err;
     LaunchOpts lo{};                               // forced wave-count build / pixel mapping / generic material set (prt_set_option)
     RenderLaunch last{};                           // what the last launch ran
+    RenderLaunch last_sub[MAX_SUB] = {};           // ... per sub-part (their grids differ by up to one tile: so can the pixel mapping)
     std::string variant;                           // ... as text (prt_kernel_variant)
 };
 
@@ -127,7 +129,7 @@ extern "C" int prt_create(int device, const prt_config* cfg, prt_ctx** out) {
         (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
         (e = hipMalloc(reinterpret_cast<void**>(&c->d_counters), (4 + 2 * prt_ctx::MAX_SUB) * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipMemset(c->d_counters, 0, (4 + 2 * prt_ctx::MAX_SUB) * sizeof(unsigned long long))) != hipSuccess ||
-        (e = hipHostMalloc(reinterpret_cast<void**>(&c->h_unfinished), 2 * prt_ctx::MAX_SUB * sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipHostMalloc(reinterpret_cast<void**>(&c->h_unfinished), (2 * prt_ctx::MAX_SUB + 1) * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming)) != hipSuccess) {
         g_global_error = std::string("prt_create: ") + hipGetErrorString(e);
         prt_destroy(c);
@@ -519,6 +521,7 @@ extern "C" int prt_render_spp(prt_ctx* c, uint32_t spp, uint32_t max_frames, con
                     fa.seed_frames = max_frames - fj[j]; fa.run_ahead = c->run_ahead;
                     fa.unfinished = c->d_counters + 4 + 2 * j;
                     fa.unfinished_host = c->h_unfinished + 2 * j + slot;
+                    if (c->test_drop_report) fa.unfinished_host = c->h_unfinished + 2 * prt_ctx::MAX_SUB;     // (tests: the report goes astray)
                     fa.tile_first = (uint32_t)j; fa.tile_stride = (uint32_t)K;
                     if (c->tile_sort && c->d_tile_cost[j] && c->sc.n_pairs > 65536u) {
                         fa.tile_order = c->have_order[j] ? c->d_tile_order[j] : nullptr;
@@ -526,7 +529,7 @@ extern "C" int prt_render_spp(prt_ctx* c, uint32_t spp, uint32_t max_frames, con
                     }
                     c->h_unfinished[2 * j + slot] = ~0ull;
                     SUBCHK(hipEventRecord(c->sub_ev0[j][slot], c->sub_stream[j]));
-                    c->last = launch_render(c->sc, c->cam, c->S, fa, c->fb, c->sub_stream[j], c->lo);
+                    c->last = c->last_sub[j] = launch_render(c->sc, c->cam, c->S, fa, c->fb, c->sub_stream[j], c->lo);
                     SUBCHK(hipEventRecord(c->sub_ev[j][slot], c->sub_stream[j]));
                     ++c->stats.launches;
                     fj[j] += n;
@@ -544,7 +547,10 @@ extern "C" int prt_render_spp(prt_ctx* c, uint32_t spp, uint32_t max_frames, con
                     if (hipEventElapsedTime(&ms, c->sub_ev0[j][slot], c->sub_ev[j][slot]) == hipSuccess) c->stats.kernel_sum_ms += ms;
                     const unsigned long long left = __atomic_load_n(c->h_unfinished + 2 * j + slot, __ATOMIC_ACQUIRE);
                     if (c->launch_log) std::fprintf(stderr, "prt launch: part %d #%u %.3f ms, %llu pixels unfinished\n", j, retired[j], ms, left);
-                    if (c->tile_sort && c->d_tile_cost[j] && c->sc.n_pairs > 65536u && !c->have_order[j] && retired[j] == 0u && !c->last.scatter && n_tiles > (unsigned)j) {
+                    // the host armed the slot with ~0 before the launch; the last wave of the launch overwrites it (render_kernel).  A launch whose
+                    // report never arrived must not be read as 1.8e19 unfinished pixels
+                    if (left == ~0ull) return abort_streams(PRT_ERR_HIP, "prt_render_spp: a launch ended without reporting its unfinished pixels");
+                    if (c->tile_sort && c->d_tile_cost[j] && c->sc.n_pairs > 65536u && !c->have_order[j] && retired[j] == 0u && !c->last_sub[j].scatter && n_tiles > (unsigned)j) {
                         // launch 0 of this sub-part is over and its stream idle: its tiles by run time, longest first, for every launch from here on
                         const unsigned grid = (n_tiles - (unsigned)j + (unsigned)K - 1u) / (unsigned)K;
                         c->h_tile_cost.resize(grid); c->h_tile_order.resize(grid);
@@ -609,7 +615,12 @@ extern "C" int prt_set_option(prt_ctx* c, const char* name, int value) {
     else if (n == "tri_q") { if (value < 0 || value > 16) return bad(); c->tri_sixteenths = (uint32_t)value; }
     else if (n == "frames_per_launch") { if (value < 0) return bad(); c->frames_per_launch = (unsigned)value; }
     else if (n == "run_ahead") { if (value < 0 || value > 1) return bad(); c->run_ahead = (uint32_t)value; }
-    else if (n == "tile_order") { if (value < 0 || value > 1) return bad(); c->tile_sort = value; for (int j = 0; j < prt_ctx::MAX_SUB; ++j) c->have_order[j] = false; }
+    else if (n == "tile_order") {
+        if (value < 0 || value > 1) return bad();
+        if (value != c->tile_sort) for (int j = 0; j < prt_ctx::MAX_SUB; ++j) c->have_order[j] = false;      // (setting it again keeps a measured order)
+        c->tile_sort = value;
+    }
+    else if (n == "test_drop_report") { if (value < 0 || value > 1) return bad(); c->test_drop_report = value != 0; }
     else return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_set_option: unknown option " + n);
     return PRT_OK;
 }

@@ -179,6 +179,8 @@ int pack_scene(const prt_config& cfg, const prt_scene_desc* s, PackedScene& out,
                     if (cn.is_leaf) {
                         if (!leaf_ok(cn)) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: leaf range out of bounds");
                         if (cn.primitive_count == 0xFFFFFFFFu) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: bad leaf");
+                        // the walk keeps the triangles a step found pending in a 25-bit count (WalkState::pend_count = both leaf children of a pair)
+                        if (cn.primitive_count >= (1u << 24)) return fail(c, PRT_ERR_UNSUPPORTED, "prt_upload_scene: a leaf of 2^24 triangles or more");
                         if (!add_leaf(cn, p.meta[2 * ch])) return fail(c, PRT_ERR_UNSUPPORTED, "prt_upload_scene: the leaves reference more than 4 x the triangles");
                         p.meta[2 * ch + 1] = cn.primitive_count;
                     } else {

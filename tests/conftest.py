@@ -22,6 +22,11 @@ def _build_once():
     if before is not None and os.path.getmtime(lib) != before:
         # (round 3: an experiment's kernel stayed in the library this way after its sources were reverted, and passed for a "slow box")
         sys.stderr.write("\n[conftest] libprt.so was REBUILT from sources newer than it: the in-tree library now is whatever the working tree holds\n")
+    # ... and it says so itself: the id compiled into the library is the hash of the working tree's sources (round 3: a library left behind
+    # by an experiment ran under the tests and the bench for a day, twice)
+    pkg = importlib.import_module(PKG_NAME)
+    if not os.environ.get("PRT_LIB"):
+        assert pkg.build_id() == pkg.source_build_id(), "libprt.so (%s) is not what the working tree (%s) builds" % (pkg.build_id(), pkg.source_build_id())
 
 
 @pytest.fixture(scope="session")

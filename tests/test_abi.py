@@ -59,3 +59,32 @@ def test_product_does_not_reference_the_oracle(prt):
     import subprocess
     out = subprocess.run(["ldd", os.path.join(pkg, "libprt.so")], stdout=subprocess.PIPE, text=True).stdout
     assert "oracle" not in out
+
+
+def test_the_library_says_what_it_was_built_from_and_the_bench_refuses_a_stale_one(prt):
+    """prt_build_id(): build.py hashes the content of every source, header and flag into the library.  Touching a header WITHOUT
+    rebuilding must be seen: the package's check raises, and bench.py leaves with a non-zero status and one line on stderr before it
+    looks for a GPU (round 3 timed an experiment's left-over library for a day, twice)."""
+    import subprocess
+    import sys
+    assert prt.build_id() == prt.source_build_id() and len(prt.build_id()) == 16
+    prt.check_build_id()
+    header = os.path.join(ROOT, "include", "prt_types.h")
+    st = os.stat(header)
+    original = open(header, "rb").read()
+    env = {k: v for k, v in os.environ.items() if k != "PRT_LIB"}
+    try:
+        with open(header, "ab") as fh:
+            fh.write(b"\n/* touched by tests/test_abi.py */\n")
+        os.utime(header, ns=(st.st_atime_ns, st.st_mtime_ns))              # (no rebuild may be triggered by this test: same mtime)
+        assert prt.source_build_id() != prt.build_id()
+        with pytest.raises(prt.StaleLibrary):
+            prt.check_build_id()
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 3, (r.returncode, r.stderr[-500:])
+        assert "refusing to time a stale library" in r.stderr and not r.stdout.strip(), (r.stdout, r.stderr[-500:])
+    finally:
+        with open(header, "wb") as fh:
+            fh.write(original)
+        os.utime(header, ns=(st.st_atime_ns, st.st_mtime_ns))
+    prt.check_build_id()

@@ -571,11 +571,17 @@ def test_expensive_tiles_first_is_invisible(prt, oracle, monkeypatch):
     r.set_camera(prt.default_camera(W, H))
     r.resize(W, H)
     out = []
-    for order in (1, 1, 0):
+    # render 0 measures the order in its first launch (8 frames) and uses it from its second on; render 1 is ONE launch per sub-part
+    # (the default launch length) and sets the option again to the same value, which must keep the measured order: its launch 0 starts
+    # with it, or nothing would say "expensive first"; render 2 runs without
+    for order, per_launch in ((1, 8), (1, 0), (0, 8)):
         r.set_option("tile_order", order)
+        r.set_option("frames_per_launch", per_launch)
         r.reset()
         r.render_spp(spp, seeds)
         assert ("expensive first" in r.kernel_variant()) == bool(order), r.kernel_variant()
+        if per_launch == 0:
+            assert r.stats().launches == 2, r.stats().launches
         c = r.counts(spp)
         out.append((r.read_state(), r.read_framebuffer(), c.segments, c.samples, c.finished_pixels))
     r.close()
@@ -584,11 +590,37 @@ def test_expensive_tiles_first_is_invisible(prt, oracle, monkeypatch):
         assert out[k][2:] == out[0][2:] and out[k][4] == W * H
 
 
+def test_a_launch_that_does_not_report_aborts_the_render(prt):
+    """prt_render_spp arms a pinned word with ~0 before every launch of a sub-part and the last wave of the launch overwrites it with the
+    number of unfinished pixels (render_kernel).  A report that never arrives (faked: option "test_drop_report" points the kernel at a spare
+    word) must end the call with PRT_ERR_HIP through abort_streams -- not be read as 1.8e19 pixels and run on to "max_frames reached" --
+    and leave the state marked unusable until prt_reset."""
+    W, H, spp = 640, 640, 2                                  # 6 400 tiles: two sub-parts
+    seeds = prt.seed_pairs(spp * 16 + 64)
+    scene = prt.HostScene("cornell_diffuse.json")
+    r = prt.Renderer(scene.config(), device=0)
+    r.upload_scene(scene)
+    r.set_camera(prt.default_camera(W, H))
+    r.resize(W, H)
+    r.set_option("test_drop_report", 1)
+    with pytest.raises(prt.PrtError) as ei:
+        r.render_spp(spp, seeds)
+    assert ei.value.code == prt.PRT_ERR_HIP and "without reporting" in str(ei.value), str(ei.value)
+    r.set_option("test_drop_report", 0)
+    with pytest.raises(prt.PrtError) as ei:                  # the state may hold run-ahead leads: unusable until reset
+        r.render_spp(spp, seeds)
+    assert ei.value.code == prt.PRT_ERR_NOT_READY
+    r.reset()
+    r.render_spp(spp, seeds)
+    assert r.counts(spp).finished_pixels == W * H
+    r.close()
+
+
 def test_options_are_validated(prt):
     scene = prt.HostScene("cornell_diffuse.json")
     r = prt.Renderer(scene.config(), device=0)
     assert r.kernel_variant() == ""
-    for name, value in (("waves", 4), ("waves", 7), ("scatter", 2), ("generic", 2), ("any_dist", 2), ("tri_q", 17), ("frames_per_launch", -1), ("tile_order", 2), ("no_such_option", 1)):
+    for name, value in (("waves", 4), ("waves", 7), ("scatter", 2), ("generic", 2), ("any_dist", 2), ("tri_q", 17), ("frames_per_launch", -1), ("tile_order", 2), ("test_drop_report", 2), ("no_such_option", 1)):
         with pytest.raises(prt.PrtError):
             r.set_option(name, value)
     r.close()

@@ -7,6 +7,6 @@ for v in "$@"; do
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
-        j=json.loads(l); print('$v', 'Msamples/s', j['value'], 'Gseg/s', j['roofline']['gsegments_per_s'], 'avg_launch_ms', j['roofline']['avg_launch_ms'])
+        j=json.loads(l); print('$v', 'Msamples/s', j['value'], 'Gseg/s', j['roofline']['gsegments_per_s'], 'avg_launch_ms', j['roofline']['avg_launch_ms'], 'build', j.get('build_id'))
 "
 done
