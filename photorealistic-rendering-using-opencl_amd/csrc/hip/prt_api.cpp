@@ -152,6 +152,7 @@ extern "C" int prt_create(int device, const prt_config* cfg, prt_ctx** out) {
     if (const char* ev = std::getenv("PRT_SCATTER")) { const int k = std::atoi(ev); if (k == 0 || k == 1) c->lo.scatter = k; }
     if (const char* ev = std::getenv("PRT_GENERIC")) c->lo.generic = std::atoi(ev) != 0 ? 1 : 0;
     if (const char* ev = std::getenv("PRT_ANY_DIST")) c->lo.any_dist = std::atoi(ev) != 0 ? 1 : 0;
+    if (const char* ev = std::getenv("PRT_POOL")) c->lo.pool = std::atoi(ev) != 0 ? 1 : 0;
     if (const char* ev = std::getenv("PRT_TRI_Q")) { const int k = std::atoi(ev); if (k >= 0 && k <= 16) c->tri_sixteenths = (uint32_t)k; }
     if (const char* ev = std::getenv("PRT_TILE_ORDER")) c->tile_sort = std::atoi(ev) != 0 ? 1 : 0;
     if (const char* ev = std::getenv("PRT_LAUNCH_LOG")) c->launch_log = std::atoi(ev) != 0;
@@ -182,6 +183,9 @@ static void free_scene(prt_ctx* c) {
 extern "C" void prt_destroy(prt_ctx* c) {
 #ifdef PT_PHASE_CLOCKS
     if (c) { (void)hipDeviceSynchronize(); prt::dump_phase_clocks(); }
+#endif
+#ifdef PT_POOL_STATS
+    if (c) { (void)hipDeviceSynchronize(); prt::dump_pool_stats(); }
 #endif
     if (!c) return;
     (void)hipSetDevice(c->device);
@@ -610,6 +614,7 @@ extern "C" int prt_set_option(prt_ctx* c, const char* name, int value) {
     else if (n == "scatter") { if (value < -1 || value > 1) return bad(); c->lo.scatter = value; }
     else if (n == "generic") { if (value < 0 || value > 1) return bad(); c->lo.generic = value; }
     else if (n == "any_dist") { if (value < 0 || value > 1) return bad(); c->lo.any_dist = value; }
+    else if (n == "pool") { if (value < 0 || value > 1) return bad(); c->lo.pool = value; }
     else if (n == "walk_min_lanes") { if (value < 0 || value > 64) return bad(); c->walk_min_lanes = (uint32_t)value; }
     else if (n == "shadow_min_lanes") { if (value < 0 || value > 64) return bad(); c->shadow_min_lanes = (uint32_t)value; }
     else if (n == "tri_q") { if (value < 0 || value > 16) return bad(); c->tri_sixteenths = (uint32_t)value; }
@@ -627,7 +632,7 @@ extern "C" int prt_set_option(prt_ctx* c, const char* name, int value) {
 
 extern "C" const char* prt_kernel_variant(prt_ctx* c) {
     if (!c) return "";
-    c->variant = std::string(c->last.name) + (c->last.waves ? " waves=" + std::to_string(c->last.waves) + (c->last.scatter ? " pixels=scattered" : (c->last.ordered ? " pixels=tiles, expensive first" : " pixels=tiles")) : "");
+    c->variant = std::string(c->last.name) + (c->last.waves ? " waves=" + std::to_string(c->last.waves) + (c->last.scatter ? " pixels=scattered" : (c->last.ordered ? " pixels=tiles, expensive first" : " pixels=tiles")) + (c->last.pool ? ", pool" : "") : "");
     return c->variant.c_str();
 }
 

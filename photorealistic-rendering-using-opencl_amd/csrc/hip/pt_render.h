@@ -16,6 +16,7 @@
 
 #include "pt_device.h"
 #include "pt_launch.h"
+#include "pt_pool.h"
 
 namespace prt {
 
@@ -282,6 +283,12 @@ static RenderLaunch launch_variant(const char* name, const DevScene& sc, const D
     RenderLaunch r;
     r.name = name; r.scatter = scatter ? 1 : 0;
     r.ordered = (!scatter && fa.tile_order && waves >= PT_BIG_WAVES) ? 1 : 0;
+    // the pool kernel (pt_pool.h) takes launches of whole tiles in index order
+    if (lo.pool && !scatter && !fa.tile_order && !fa.tile_cost && fa.width < 65536 && fa.full_height < 65536) {
+        FrameArgs fp = fa;
+        fp.scatter = 0u;
+        if (launch_pool<MATS, MEDIUM, PT_POOL_OCC>(sc, cam, S, fp, fb, stream, grid)) { r.waves = PT_BIG_WAVES; r.pool = 1; return r; }
+    }
 #if defined(PT_DEV_ONE_VARIANT) && !defined(PT_DEV_BOTH_WAVES)
     r.waves = PT_BIG_WAVES;
     launch_variant_w<MATS, MEDIUM, PT_BIG_WAVES>(sc, cam, S, fa, fb, stream, grid, scatter);

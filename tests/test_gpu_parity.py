@@ -457,6 +457,41 @@ def test_pixel_to_wave_mappings_match_golden(prt, oracle, scatter):
     r.close()
 
 
+@pytest.mark.parametrize("variant", list(VARIANTS))
+def test_pool_kernel_matches_golden(prt, oracle, variant):
+    """render_kernel_pool (pt_pool.h, prt_set_option "pool"): shading waves that only take the root step of a walk, walker waves for the
+    rest, whole pixel contexts migrating between lanes through a pool in LDS -- which lane, which wave and in which order a pixel's
+    segments run is anybody's guess, the pixel's bits are not.  Every golden (frame mode), a ragged frame against the oracle and the
+    samples-per-pixel golden (run-ahead, freezing, the launch's report)."""
+    ran = _golden_through(prt, oracle, variant, "pool", pool=1, scatter=0)
+    assert "pool" in ran, ran
+
+
+def test_pool_kernel_ragged_frame_and_spp_mode(prt, oracle):
+    variant = "cornell_mixed"
+    W2, H2, frames2 = 61, 43, 20                                  # neither a multiple of 8; 48 tiles = 10 workgroups of 5 shading waves, the last one short
+    scene, cfg, cam2, env, r = _setup(prt, variant, W2, H2)
+    r.set_option("pool", 1)
+    r.set_option("scatter", 0)
+    seeds = prt.seed_pairs(frames2)
+    ostate, oimg = oracle.Restatement().render(cfg, scene.desc, cam2, W2, H2, seeds, env=env)
+    r.render_frames(seeds)
+    assert "pool" in r.kernel_variant()
+    _assert_same(oracle, ostate, oimg, r.read_state(), r.read_framebuffer(), "pool, ragged frame")
+    r.close()
+    gs = np.load(os.path.join(GOLDEN, "cornell_diffuse_spp.npz"))
+    for per_launch in (0, 7):                                     # one launch; several (leads of the run-ahead carried from launch to launch)
+        scene, cfg, cam, env, r = _setup(prt, "cornell_diffuse", int(gs["width"]), int(gs["height"]))
+        r.set_option("pool", 1)
+        r.set_option("scatter", 0)
+        r.set_option("frames_per_launch", per_launch)
+        r.render_spp(int(gs["spp"]), prt.seed_pairs(int(gs["frames"])))
+        assert "pool" in r.kernel_variant()
+        sstate = np.ascontiguousarray(gs["state"]).view(oracle.PATH_STATE_DTYPE).reshape(-1)
+        _assert_same(oracle, sstate, gs["image"], r.read_state(), r.read_framebuffer(), "pool, spp golden, %d frames per launch" % per_launch)
+        r.close()
+
+
 @pytest.mark.parametrize("waves", [5, 6])
 @pytest.mark.parametrize("scatter", [0, 1])
 @pytest.mark.parametrize("variant", ["cornell_diffuse", "cornell_media_hg", "cornell_sdf", "cornell_mixed", "cornell_coat", "cornell_roughdiel"])
