@@ -1366,6 +1366,7 @@ struct Lane {
     unsigned w2 : 1;         // the closest-hit walk in flight is the probe (W2), else the path ray (W1)
     unsigned occluded : 1;
     unsigned sh_vertex : 1;  // PT_MATS_ENVIS: the shadow ray starts at the vertex (= origin of the probe), not where the probe ended
+    unsigned posted : 1;     // render_kernel_rp (pt_pool.h): the lane's ray is with the workgroup's walker waves
 };
 
 // position of the hit in L.h: intersect_scene's `ray.pos = ray.origin + ray.dir * t` (same operations, same bits) on the ray that was walked
@@ -1381,6 +1382,7 @@ PT_DEV void lane_init(Lane& L) {
     L.f = 0u; L.stage = ST_READY;
     L.begun = L.fresh = L.w2 = L.occluded = false;
     L.sh_vertex = false;
+    L.posted = false;
 }
 
 // may this lane start (or go on with) a segment?  The "N spp" rule freezes a pixel at a segment boundary.

@@ -194,8 +194,8 @@ void dump_pool_stats() {
     unsigned long long h[32] = {0};
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_pool_stats), sizeof(h)) != hipSuccess) return;
     const double it = h[0] ? (double)h[0] : 1.0;
-    fprintf(stderr, "pool stats: shading-wave iterations %llu, occupied lanes %.1f, runnable %.1f, waiting for a slot %.1f, idle sleeps %llu\n", h[0], h[1] / it, h[3] / it, h[8] / it, h[2]);
-    fprintf(stderr, "pool stats: park requests %llu granted %llu (%.2f per iteration); empty-lane polls %llu taken %llu\n", h[4], h[5], h[5] / it, h[6], h[7]);
+    fprintf(stderr, "pool stats: shading-wave iterations %llu, runnable lanes %.1f, lanes waiting for a walker %.1f; rays posted %llu (%.2f per iteration), answers taken %llu\n",
+            h[0], h[3] / it, h[8] / it, h[4], h[4] / it, h[7]);
     const double st = h[20] ? (double)h[20] : 1.0;
     fprintf(stderr, "pool stats: walker loops %llu, refill tries %llu got %llu rays, sleeps %llu; steps %llu at %.1f lanes (box %.1f), triangle units %llu\n",
             h[16], h[17], h[18], h[19], h[20], h[21] / st, h[22] / st, h[23]);

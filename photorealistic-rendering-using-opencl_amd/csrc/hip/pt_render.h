@@ -283,11 +283,14 @@ static RenderLaunch launch_variant(const char* name, const DevScene& sc, const D
     RenderLaunch r;
     r.name = name; r.scatter = scatter ? 1 : 0;
     r.ordered = (!scatter && fa.tile_order && waves >= PT_BIG_WAVES) ? 1 : 0;
-    // the pool kernel (pt_pool.h) takes launches of whole tiles in index order
-    if (lo.pool && !scatter && !fa.tile_order && !fa.tile_cost && fa.width < 65536 && fa.full_height < 65536) {
+    // render_kernel_rp (pt_pool.h): the same launch -- same tiles or scattered pixels, same order -- with the deep walks on walker waves
+    if (lo.pool) {
         FrameArgs fp = fa;
-        fp.scatter = 0u;
-        if (launch_pool<MATS, MEDIUM, PT_POOL_OCC>(sc, cam, S, fp, fb, stream, grid)) { r.waves = PT_BIG_WAVES; r.pool = 1; return r; }
+        fp.scatter = scatter ? 1u : 0u;
+        const bool ordered = !scatter && (fa.tile_order || fa.tile_cost);
+        const bool ok = ordered ? launch_rp<MATS, MEDIUM, PT_BIG_WAVES, true>(sc, cam, S, fp, fb, stream, grid)
+                                : launch_rp<MATS, MEDIUM, PT_BIG_WAVES, false>(sc, cam, S, fp, fb, stream, grid);
+        if (ok) { r.waves = PT_BIG_WAVES; r.pool = 1; return r; }
     }
 #if defined(PT_DEV_ONE_VARIANT) && !defined(PT_DEV_BOTH_WAVES)
     r.waves = PT_BIG_WAVES;

@@ -457,39 +457,65 @@ def test_pixel_to_wave_mappings_match_golden(prt, oracle, scatter):
     r.close()
 
 
+@pytest.mark.parametrize("scatter", [0, 1])
 @pytest.mark.parametrize("variant", list(VARIANTS))
-def test_pool_kernel_matches_golden(prt, oracle, variant):
-    """render_kernel_pool (pt_pool.h, prt_set_option "pool"): shading waves that only take the root step of a walk, walker waves for the
-    rest, whole pixel contexts migrating between lanes through a pool in LDS -- which lane, which wave and in which order a pixel's
-    segments run is anybody's guess, the pixel's bits are not.  Every golden (frame mode), a ragged frame against the oracle and the
-    samples-per-pixel golden (run-ahead, freezing, the launch's report)."""
-    ran = _golden_through(prt, oracle, variant, "pool", pool=1, scatter=0)
-    assert "pool" in ran, ran
+def test_ray_pool_kernel_matches_golden(prt, oracle, variant, scatter):
+    """render_kernel_rp (pt_pool.h, prt_set_option "pool"): shading waves that take only the step at the root of a walk and post the rays
+    that go deeper into a pool in LDS, walker waves that walk the rays of the whole workgroup -- who walks a ray, next to which other
+    rays and when is anybody's guess, the answer is not.  Every golden, both pixel mappings, what ran read back."""
+    ran = _golden_through(prt, oracle, variant, "ray pool, scatter=%d" % scatter, pool=1, scatter=scatter)
+    assert "pool" in ran and ("pixels=scattered" if scatter else "pixels=tiles") in ran, ran
 
 
-def test_pool_kernel_ragged_frame_and_spp_mode(prt, oracle):
+def test_ray_pool_kernel_ragged_frame_and_spp_mode(prt, oracle):
     variant = "cornell_mixed"
     W2, H2, frames2 = 61, 43, 20                                  # neither a multiple of 8; 48 tiles = 10 workgroups of 5 shading waves, the last one short
-    scene, cfg, cam2, env, r = _setup(prt, variant, W2, H2)
-    r.set_option("pool", 1)
-    r.set_option("scatter", 0)
-    seeds = prt.seed_pairs(frames2)
-    ostate, oimg = oracle.Restatement().render(cfg, scene.desc, cam2, W2, H2, seeds, env=env)
-    r.render_frames(seeds)
-    assert "pool" in r.kernel_variant()
-    _assert_same(oracle, ostate, oimg, r.read_state(), r.read_framebuffer(), "pool, ragged frame")
-    r.close()
+    for scatter in (0, 1):
+        scene, cfg, cam2, env, r = _setup(prt, variant, W2, H2)
+        r.set_option("pool", 1)
+        r.set_option("scatter", scatter)
+        seeds = prt.seed_pairs(frames2)
+        ostate, oimg = oracle.Restatement().render(cfg, scene.desc, cam2, W2, H2, seeds, env=env)
+        r.render_frames(seeds)
+        assert "pool" in r.kernel_variant()
+        _assert_same(oracle, ostate, oimg, r.read_state(), r.read_framebuffer(), "ray pool, ragged frame, scatter=%d" % scatter)
+        r.close()
     gs = np.load(os.path.join(GOLDEN, "cornell_diffuse_spp.npz"))
     for per_launch in (0, 7):                                     # one launch; several (leads of the run-ahead carried from launch to launch)
         scene, cfg, cam, env, r = _setup(prt, "cornell_diffuse", int(gs["width"]), int(gs["height"]))
         r.set_option("pool", 1)
-        r.set_option("scatter", 0)
         r.set_option("frames_per_launch", per_launch)
         r.render_spp(int(gs["spp"]), prt.seed_pairs(int(gs["frames"])))
         assert "pool" in r.kernel_variant()
         sstate = np.ascontiguousarray(gs["state"]).view(oracle.PATH_STATE_DTYPE).reshape(-1)
-        _assert_same(oracle, sstate, gs["image"], r.read_state(), r.read_framebuffer(), "pool, spp golden, %d frames per launch" % per_launch)
+        _assert_same(oracle, sstate, gs["image"], r.read_state(), r.read_framebuffer(), "ray pool, spp golden, %d frames per launch" % per_launch)
         r.close()
+
+
+def test_ray_pool_kernel_through_the_big_tree(prt, oracle, monkeypatch):
+    """the 871 k-triangle stand-in (22 stack levels, nearly every ray goes past the root; launches that take their tiles in the
+    launcher's order and report what they cost): the ray pool's render equals render_kernel's bit for bit, in samples-per-pixel mode"""
+    W, H, spp = 2560, 1440, 2
+    monkeypatch.setenv("PRT_FRAMES_PER_LAUNCH", "8")
+    prt.ensure_dragon_standin()
+    seeds = prt.seed_pairs(spp * 16 + 64)
+    scene = prt.HostScene("cornell_dragon.json")
+    r = prt.Renderer(scene.config(), device=0)
+    r.upload_scene(scene)
+    r.set_camera(prt.default_camera(W, H))
+    r.resize(W, H)
+    out = []
+    for pool in (0, 1):
+        r.set_option("pool", pool)
+        r.reset()
+        r.render_spp(spp, seeds)
+        ran = r.kernel_variant()
+        assert ("pool" in ran) == bool(pool) and "expensive first" in ran, ran
+        c = r.counts(spp)
+        out.append((r.read_state(), r.read_framebuffer(), c.segments, c.samples, c.finished_pixels))
+    r.close()
+    _assert_same(oracle, out[0][0], out[0][1], out[1][0], out[1][1], "ray pool vs render_kernel through the big tree")
+    assert out[1][2:] == out[0][2:] and out[1][4] == W * H
 
 
 @pytest.mark.parametrize("waves", [5, 6])

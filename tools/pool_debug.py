@@ -17,7 +17,7 @@ out = []
 for pool in (0, 1):
     r = prt.Renderer(cfg, device=0)
     r.upload_scene(scene); r.set_camera(cam); r.resize(W, H)
-    r.set_option("pool", pool); r.set_option("scatter", 0)
+    r.set_option("pool", pool)
     r.render_frames(seeds)
     st = r.read_state().view(prt.PATH_STATE_DTYPE).reshape(H, W)
     print("pool", pool, r.kernel_variant(), "kernel ms", r.stats().kernel_ms)
