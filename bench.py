@@ -15,15 +15,15 @@ image of that frame), and ONE RCCL collective per step -- a gather of every rank
 puts the framebuffer together there, inside the timed region.  By default rank 0 then renders
 the whole frame alone (untimed) and the JSON line says whether the merged frame equals it bit for bit.
 
-Scaling.  Pixels are independent units: the path shards with no data-path exchange, so the N-GPU line is a WEAK-scaling
-measurement (default): the per-GPU work is fixed -- the same view rendered with N x the pixels of the base frame (both
-dimensions x sqrt(N): 2720x1530, 3840x2160, 5424x3051 for N = 2, 4, 8; same camera, same spp, hence the same cost per
-pixel), every rank renders its interleaved row blocks, one gather per step.  N = 1 is BASELINE config 2 itself.
-The same run also reports, as `fixed_frame`, the FIXED base frame (1920x1080, 1024 spp) split N ways (strong scaling, one
-step): at 1080p that stops scaling early for a structural reason measured in DESIGN.md s5 -- the frame has 32 400 waves of
-pixels, eight MI355X hold 49 152 resident waves, so the run time falls to the sequential chain of the slowest tile
-(spp x path length segments, one after the other), not to work / N.  `--scaling strong` makes that split the headline line
-instead.  With N = 8 the run adds BASELINE config 5 -- the 871 k-triangle stand-in at 3840x2160, 8-way split -- as `config5`.
+Scaling.  The N-GPU line is BASELINE's own frame: the FIXED 1920x1080 x 1024 spp frame of config 2 split N ways (strong scaling;
+`metric` names the frame that was rendered, `scaling` says "strong"), every rank its interleaved row blocks, one gather per step,
+the merged frame checked against the one GPU's.  That stops scaling early for a structural reason measured in DESIGN.md s5: the
+frame is 32 400 waves of pixels, one MI355X holds 6 144, so from N = 4 on a rank's share is one round of waves and its run time the
+sequential chain of its slowest pixel (spp x path length segments, one after the other), not work / N.  Pixels are independent
+units, so the path shards with no data-path exchange and its WEAK scaling -- fixed work per GPU: the same view with N x the pixels
+(both dimensions x sqrt(N): 2720x1530, 3840x2160, 5424x3051; same camera and spp, hence the same cost per pixel) -- rides along as
+the sub-record `weak` (one step).  `--scaling weak` makes that the headline line instead (its `metric` then names the bigger
+frame).  With N = 8 the run adds BASELINE config 5 -- the 871 k-triangle stand-in at 3840x2160, 8-way split -- as `config5`, verified.
 
 The JSON line also carries
   roofline      the dominant kernel (render_kernel) priced in ALGORITHMIC bytes: 240 B per pixel
@@ -170,10 +170,10 @@ def main():
     ap.add_argument("--scene", default="cornell_diffuse.json")
     ap.add_argument("--env", default="", choices=["", "sky"], help="sky = the procedural 1024x512 HDR stand-in (configs 3, 4)")
     ap.add_argument("--phase", default="isotropic", choices=["isotropic", "hg", "rayleigh"], help="phase function of the global medium (config 4)")
-    ap.add_argument("--scaling", default="weak", choices=["strong", "weak"],
-                    help="N > 1: weak (default) = N x the pixels (frame x sqrt(N) per dimension, fixed work per GPU); strong = the FIXED base frame split N ways")
-    ap.add_argument("--no-fixed-frame", action="store_true",
-                    help="N > 1, weak scaling: skip the extra one-step run of the fixed base frame split N ways (`fixed_frame`)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: strong (default) = the FIXED base frame split N ways (BASELINE's frame); weak = N x the pixels (frame x sqrt(N) per dimension, fixed work per GPU)")
+    ap.add_argument("--no-weak", action="store_true",
+                    help="N > 1: skip the extra one-step run of the weak-scaling frame (`weak`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true",
                     help="N > 1: skip the check that rank 0's merged frame equals, bit for bit, the frame one GPU renders alone")
@@ -229,11 +229,11 @@ def main():
     verify = world > 1 and not a.no_verify
     res = run_workload(prt, par, torch, dist, np, a, world, rank, local_rank, a.scene, a.width, a.height, a.spp, a.env, a.phase,
                        a.scaling, a.steps, a.warmup, verify)
-    # beside the weak-scaling line: the fixed base frame split N ways (strong scaling), one step
-    res_fixed = None
-    if world > 1 and a.scaling == "weak" and not a.no_fixed_frame:
-        res_fixed = run_workload(prt, par, torch, dist, np, a, world, rank, local_rank, a.scene, a.width, a.height, a.spp, a.env, a.phase,
-                                 "strong", 1, 1, False)
+    # beside the line of BASELINE's frame: the other kind of scaling, one step
+    res_other = None
+    if world > 1 and not a.no_weak:
+        res_other = run_workload(prt, par, torch, dist, np, a, world, rank, local_rank, a.scene, a.width, a.height, a.spp, a.env, a.phase,
+                                 "weak" if a.scaling == "strong" else "strong", 1, 1, False)
     # BASELINE config 5 is defined on 8 GPUs: the 871 k-triangle stand-in at 3840x2160, 8-way tile split + framebuffer merge
     res5 = None
     if (world == 8 or (world > 1 and os.environ.get("PRT_BENCH_CONFIG5") == "1")) and a.config5_spp > 0 and a.scene == "cornell_diffuse.json":
@@ -278,7 +278,7 @@ def main():
             except Exception:
                 valu = None
         out = {
-            "metric": "Msamples/s (width x height x spp / s) at %dx%d" % (a.width, a.height),
+            "metric": "Msamples/s (width x height x spp / s) at %dx%d" % (W, H),
             "value": round(res["msamples"], 3),
             "unit": "Msamples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -313,9 +313,12 @@ def main():
         }
         if res["verified"] is not None:
             out["config"]["merged_frame_equals_single_gpu_render"] = res["verified"]
-        if res_fixed is not None:
-            out["fixed_frame"] = {"workload": "%s %dx%d %dspp split over %d ranks (strong scaling of the base frame, one step)" % (a.scene, a.width, a.height, a.spp, world),
-                                  "value": round(res_fixed["msamples"], 3), "unit": "Msamples/s", "ms_per_step": round(res_fixed["ms_per_step"], 3)}
+        if res_other is not None:
+            key = "weak" if a.scaling == "strong" else "fixed_frame"
+            out[key] = {"workload": "%s %dx%d %dspp over %d ranks (%s, one step)" % (
+                            a.scene, res_other["W"], res_other["H"], a.spp, world,
+                            "weak scaling: %d x the pixels of the base frame, fixed work per GPU" % world if key == "weak" else "strong scaling of the base frame"),
+                        "value": round(res_other["msamples"], 3), "unit": "Msamples/s", "ms_per_step": round(res_other["ms_per_step"], 3)}
         if res5 is not None:
             out["config5"] = {"workload": "scenes/cornell_dragon (871 k-triangle stand-in) 3840x2160 %dspp, %d x MI355X tile split + RCCL framebuffer merge "
                                           "(BASELINE config 5 at a reduced spp: the full 8192 spp is %d x this work)" % (res5["spp"], world, 8192 // max(res5["spp"], 1)),

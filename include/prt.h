@@ -203,6 +203,11 @@ int prt_set_walk_min_lanes(prt_ctx* ctx, uint32_t lanes);
  *   "tile_order"        1 | 0   prt_render_spp starts the tiles whose waves ran longest in a sub-part's first launch first in its later
  *                               launches (and renders, until scene, camera or frame change; setting the option to the value it has
  *                               keeps a measured order); 0: in index order
+ *   "pix_per_wave"      0 (default: chosen per launch) | 64 | 32 | 16   pixels a wave of the render kernel renders (its other lanes idle).  Launches
+ *                               that leave wave slots of the chip empty -- one rank's share of a frame split N ways, a small frame -- finish sooner
+ *                               with more waves of fewer pixels: a wave lasts as long as the slowest of its pixels' chains of segments
+ *   "pool"              0 | 1   1: render_kernel_rp (csrc/hip/pt_pool.h): workgroups of shading waves that post the rays that go deeper than the root
+ *                               of the tree to walker waves through LDS.  Bit-exact, measured slower than the default kernel: off
  *   "test_drop_report"  0 | 1   tests only: the launches of prt_render_spp report their unfinished pixels into a spare word, so that the
  *                               call sees a launch end without a report (PRT_ERR_HIP, state unusable until prt_reset) */
 int prt_set_option(prt_ctx* ctx, const char* name, int value);

@@ -152,6 +152,7 @@ extern "C" int prt_create(int device, const prt_config* cfg, prt_ctx** out) {
     if (const char* ev = std::getenv("PRT_SCATTER")) { const int k = std::atoi(ev); if (k == 0 || k == 1) c->lo.scatter = k; }
     if (const char* ev = std::getenv("PRT_GENERIC")) c->lo.generic = std::atoi(ev) != 0 ? 1 : 0;
     if (const char* ev = std::getenv("PRT_ANY_DIST")) c->lo.any_dist = std::atoi(ev) != 0 ? 1 : 0;
+    if (const char* ev = std::getenv("PRT_PIX_PER_WAVE")) { const int k = std::atoi(ev); if (k == 64 || k == 32 || k == 16) c->lo.pix_per_wave = k; }
     if (const char* ev = std::getenv("PRT_POOL")) c->lo.pool = std::atoi(ev) != 0 ? 1 : 0;
     if (const char* ev = std::getenv("PRT_TRI_Q")) { const int k = std::atoi(ev); if (k >= 0 && k <= 16) c->tri_sixteenths = (uint32_t)k; }
     if (const char* ev = std::getenv("PRT_TILE_ORDER")) c->tile_sort = std::atoi(ev) != 0 ? 1 : 0;
@@ -389,7 +390,7 @@ static FrameArgs frame_args(prt_ctx* c, uint32_t first_frame, uint32_t n, const 
     fa.seed_frames = n; fa.run_ahead = 0;
     fa.unfinished = count ? c->d_counters : nullptr;
     fa.unfinished_host = nullptr;
-    fa.tile_first = 0; fa.tile_stride = 1; fa.scatter = 0;
+    fa.tile_first = 0; fa.tile_stride = 1; fa.scatter = 0; fa.sub_shift = 0;
     fa.tile_order = nullptr; fa.tile_cost = nullptr;
     // 0 = by launch (pt_kernels.hip launch_variant_w: the scattered-pixel launches and the medium variants 6, the others 8; shadow
     // phases in lock step in small trees, bounded like the closest-hit phases in big ones)
@@ -532,6 +533,8 @@ extern "C" int prt_render_spp(prt_ctx* c, uint32_t spp, uint32_t max_frames, con
                         fa.tile_cost = (!c->have_order[j] && issued[j] == 0u) ? c->d_tile_cost[j] : nullptr;
                     }
                     c->h_unfinished[2 * j + slot] = ~0ull;
+                    // (a tile's cost is the maximum over its waves -- atomicMax in the kernel: the measuring launch starts from zero)
+                    if (fa.tile_cost) SUBCHK(hipMemsetAsync(c->d_tile_cost[j], 0, (size_t)render_tile_count(c->width, c->rows) * sizeof(uint32_t), c->sub_stream[j]));
                     SUBCHK(hipEventRecord(c->sub_ev0[j][slot], c->sub_stream[j]));
                     c->last = c->last_sub[j] = launch_render(c->sc, c->cam, c->S, fa, c->fb, c->sub_stream[j], c->lo);
                     SUBCHK(hipEventRecord(c->sub_ev[j][slot], c->sub_stream[j]));
@@ -614,6 +617,7 @@ extern "C" int prt_set_option(prt_ctx* c, const char* name, int value) {
     else if (n == "scatter") { if (value < -1 || value > 1) return bad(); c->lo.scatter = value; }
     else if (n == "generic") { if (value < 0 || value > 1) return bad(); c->lo.generic = value; }
     else if (n == "any_dist") { if (value < 0 || value > 1) return bad(); c->lo.any_dist = value; }
+    else if (n == "pix_per_wave") { if (value != 0 && value != 64 && value != 32 && value != 16) return bad(); c->lo.pix_per_wave = value; }
     else if (n == "pool") { if (value < 0 || value > 1) return bad(); c->lo.pool = value; }
     else if (n == "walk_min_lanes") { if (value < 0 || value > 64) return bad(); c->walk_min_lanes = (uint32_t)value; }
     else if (n == "shadow_min_lanes") { if (value < 0 || value > 64) return bad(); c->shadow_min_lanes = (uint32_t)value; }
@@ -632,7 +636,7 @@ extern "C" int prt_set_option(prt_ctx* c, const char* name, int value) {
 
 extern "C" const char* prt_kernel_variant(prt_ctx* c) {
     if (!c) return "";
-    c->variant = std::string(c->last.name) + (c->last.waves ? " waves=" + std::to_string(c->last.waves) + (c->last.scatter ? " pixels=scattered" : (c->last.ordered ? " pixels=tiles, expensive first" : " pixels=tiles")) + (c->last.pool ? ", pool" : "") : "");
+    c->variant = std::string(c->last.name) + (c->last.waves ? " waves=" + std::to_string(c->last.waves) + (c->last.scatter ? " pixels=scattered" : (c->last.ordered ? " pixels=tiles, expensive first" : " pixels=tiles")) + (c->last.pix_per_wave != 64 ? ", " + std::to_string(c->last.pix_per_wave) + " per wave" : "") + (c->last.pool ? ", pool" : "") : "");
     return c->variant.c_str();
 }
 

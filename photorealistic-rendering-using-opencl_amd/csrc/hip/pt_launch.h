@@ -13,10 +13,11 @@ struct LaunchOpts {
     int scatter = -1;       // -1: chosen per launch; 0: one 8x8 tile per wave; 1: a wave's pixels scattered over the launch's tiles
     int generic = 0;        // 1: the run-time-dispatched material set even where the scene's own set is compiled
     int any_dist = 0;       // 1: the set's instance that carries every microfacet distribution even where the scene uses one (PT_MATS_DISTS)
+    int pix_per_wave = 0;   // 0: chosen per launch; 64 / 32 / 16: pixels a wave renders (FrameArgs::sub_shift)
     int pool = 0;           // 1: render_kernel_pool (pt_pool.h: shading waves + walker waves around a pool of parked contexts) where a launch can take it
 };
 // what a launch ran: kernel variant, wave-count build, pixel-to-wave mapping (prt_kernel_variant)
-struct RenderLaunch { const char* name = ""; int waves = 0; int scatter = 0; int ordered = 0; int pool = 0; };   // ordered: the tiles were taken in the launcher's order
+struct RenderLaunch { const char* name = ""; int waves = 0; int scatter = 0; int ordered = 0; int pool = 0; int pix_per_wave = 64; };   // ordered: the tiles were taken in the launcher's order
 
 // launches the scene-specialised variant (the AOT analogue of the reference's per-scene program
 // build, include/CL/cl_kernel.h:226-345)

@@ -146,6 +146,9 @@ struct FrameArgs {
     const uint32_t* tile_order;             // null, or a permutation of the launch's k: workgroup g renders tile k = tile_order[g] (the expensive
                                             // tiles first: the hardware starts workgroups in index order, and a launch ends with its last tile)
     uint32_t* tile_cost;                    // null, or where the wave of tile k leaves the iterations it took (tile_cost[k]): what the tile costs
+    uint32_t sub_shift;                     // set by the launcher: a wave renders 64 >> sub_shift pixels (its other lanes idle): 2^sub_shift waves per tile.
+                                            // For launches that leave wave slots of the chip empty (one rank's share of a frame): pixels are independent, so
+                                            // more waves with fewer pixels each finish sooner -- a wave lasts as long as its slowest lane
     uint32_t scatter;                       // set by the launcher: lane l of wave g renders pixel l of tile (l * waves + g) / 64 ...
     uint32_t walk_min_lanes;                // lane machine: a closest-hit walk phase of a wave ends once fewer lanes than this are still walking
     uint32_t shadow_min_lanes;              // ... and an any-hit (shadow ray) phase below this many

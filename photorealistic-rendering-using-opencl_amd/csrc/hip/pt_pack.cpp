@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <utility>
 
@@ -140,8 +141,43 @@ int pack_scene(const prt_config& cfg, const prt_scene_desc* s, PackedScene& out,
             std::vector<uint32_t> order;
             const char* e_order = std::getenv("PRT_PAIR_ORDER");
             const bool dfs = e_order ? (std::strcmp(e_order, "dfs") == 0) : (N > 65536u);
+            // "treelet[:K]": subtrees of at most K pairs (K x 64 B contiguous) grown from their root by surface area -- the child a ray is
+            // most likely to visit next joins first --, the subtrees hanging off a treelet's frontier laid out behind it, depth-first
+            unsigned treelet_k = 0;
+            if (e_order && std::strncmp(e_order, "treelet", 7) == 0) { treelet_k = e_order[7] == ':' ? (unsigned)std::atoi(e_order + 8) : 512u; if (treelet_k < 2u) treelet_k = 2u; }
             order.reserve(N / 2 + 1);
-            if (!dfs) {
+            if (treelet_k) {
+                auto area = [&](uint32_t n) {
+                    const float* b = nodes[n].bounds;
+                    const double dx = (double)b[1] - b[0], dy = (double)b[3] - b[2], dz = (double)b[5] - b[4];
+                    return dx * dy + dy * dz + dz * dx;
+                };
+                std::vector<uint32_t> roots{0};
+                std::vector<std::pair<double, uint32_t>> frontier;        // max-heap on area
+                while (!roots.empty()) {
+                    const uint32_t r = roots.back();
+                    roots.pop_back();
+                    frontier.clear();
+                    frontier.push_back({area(r), r});
+                    unsigned count = 0;
+                    while (!frontier.empty() && count < treelet_k) {
+                        std::pop_heap(frontier.begin(), frontier.end());
+                        const uint32_t n = frontier.back().second;
+                        frontier.pop_back();
+                        if (n >= N || pair_of[n] != 0xFFFFFFFFu || order.size() >= N) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: BVH is not a tree");
+                        pair_of[n] = (uint32_t)order.size();
+                        order.push_back(n);
+                        ++count;
+                        const uint32_t fc = nodes[n].first_child_or_primitive;
+                        if ((uint64_t)fc + 1 >= N) return fail(c, PRT_ERR_INVALID_ARGUMENT, "prt_upload_scene: BVH child index out of range");
+                        for (uint32_t ch = fc; ch <= fc + 1; ++ch)
+                            if (!nodes[ch].is_leaf) { frontier.push_back({area(ch), ch}); std::push_heap(frontier.begin(), frontier.end()); }
+                    }
+                    // what is left on the frontier are the roots of the treelets below this one: the biggest first (popped last from `roots`... pushed smallest first)
+                    std::sort(frontier.begin(), frontier.end());
+                    for (const auto& f : frontier) roots.push_back(f.second);
+                }
+            } else if (!dfs) {
                 order.push_back(0);
                 pair_of[0] = 0;
                 for (size_t head = 0; head < order.size(); ++head) {

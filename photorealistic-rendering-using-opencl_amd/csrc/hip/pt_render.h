@@ -38,6 +38,9 @@ using namespace dev;
 #ifndef PT_WAVES
 #define PT_WAVES 5
 #endif
+#ifndef PT_SUBWAVE_SLOTS
+#define PT_SUBWAVE_SLOTS 6144u    // launch_sub_shift: waves the launches in flight may add up to with fewer pixels per wave
+#endif
 #define PT_BLOCK 64         // threads per workgroup: ONE wave.  A workgroup's slot (LDS, dispatch) frees only when its last wave
                             // ends, and waves over the mesh run ~3x longer than waves over a wall: one-wave groups +4 % over 256
 
@@ -73,20 +76,23 @@ __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene 
     // Every wave then gets its share of the expensive regions: a launch with few rounds of waves no longer waits for the
     // tiles over the mesh (512x512: +39 %); a big frame loses the coherence of neighbouring pixels' first segments (-17 %).
     // (not scattered: one tile per wave, and which one is the launcher's choice -- FrameArgs::tile_order)
-    const unsigned tile_k = (ORDER && !fa.scatter && fa.tile_order) ? fa.tile_order[blockIdx.x] : blockIdx.x;
+    // fa.sub_shift: the wave renders P = 64 >> sub_shift pixels, 2^sub_shift waves share a tile (or, scattered, the launch's pixels)
+    const unsigned P = 64u >> fa.sub_shift;
+    const unsigned tile_g = blockIdx.x >> fa.sub_shift;
+    const unsigned tile_k = (ORDER && !fa.scatter && fa.tile_order) ? fa.tile_order[tile_g] : tile_g;
     // What a tile costs is reported as the wave's ITERATIONS, not its clock ticks: a time stamp taken here (`s_memtime`, as intrinsic or as
     // inline assembly) counts for the compiler as something every later load may depend on, and such a load cannot go through the scalar
     // cache -- the quads, spheres, materials and the root of the tree all came through the vector-memory path in the first build of this
     // (2.2 x its instructions, 6 % of the scalar loads left; found with the instruction counters, the clock said +-0).
     unsigned iterations = 0u;
-    const unsigned vpix = fa.scatter ? (unsigned)lane * gridDim.x + blockIdx.x : tile_k * 64u + (unsigned)lane;
+    const unsigned vpix = fa.scatter ? (unsigned)lane * gridDim.x + blockIdx.x : tile_k * 64u + (blockIdx.x & ((1u << fa.sub_shift) - 1u)) * P + (unsigned)lane;
     const unsigned tile = (vpix >> 6) * fa.tile_stride + fa.tile_first;
     const int tl = (int)(vpix & 63u);
     const int tile_x = (int)(tile % (unsigned)tiles_x), tile_y = (int)(tile / (unsigned)tiles_x);
     const int lx = tile_x * 8 + (tl & 7);
     const int ly = tile_y * 8 + (tl >> 3);
     // a lane outside the frame (edge tiles) idles through the kernel: every wave reaches the end, where the last one reports
-    const bool in_frame = lx < fa.width && ly < fa.rows;
+    const bool in_frame = (unsigned)lane < P && lx < fa.width && ly < fa.rows;
     const size_t id = in_frame ? (size_t)ly * (size_t)fa.width + (size_t)lx : 0;
     const int gx = lx;
     const int gy = fa.row0 + (ly / fa.block_rows * fa.n_parts + fa.part) * fa.block_rows + ly % fa.block_rows;
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene 
         const float ns = (MATS & PT_MATS_VIEW) ? 1.0f : (float)L.samples;      // write_imagef, main.cl:159 (a debug view: :161)
         fb[id] = make_float4(L.acc[0] / ns, L.acc[1] / ns, L.acc[2] / ns, L.acc[3] / ns);
     }
-    if (ORDER && !fa.scatter && fa.tile_cost && lane == 0) fa.tile_cost[tile_k] = iterations;
+    if (ORDER && !fa.scatter && fa.tile_cost && lane == 0) atomicMax(&fa.tile_cost[tile_k], iterations);     // (the longest of the tile's waves)
     if (fa.unfinished) {
         const bool unfinished = in_frame && !(fa.spp_limit && L.reset && L.samples >= fa.spp_limit);
         const unsigned long long m = __ballot(unfinished);
@@ -241,6 +247,22 @@ static inline unsigned launch_grid(const DevScene& sc, const FrameArgs& fa, cons
     scatter = lo.scatter >= 0 ? lo.scatter != 0 : grid <= (sc.n_pairs > 65536u ? 24576u : 6144u);
     return grid;
 }
+// Pixels per wave (FrameArgs::sub_shift).  A launch whose tiles leave wave slots of the chip empty -- one rank's share of a frame
+// split N ways, a small frame -- lasts as long as its slowest wave, and a wave as long as its slowest lane's chain of segments (every
+// frame of a pixel follows its previous one: DESIGN.md s5); with 32 or 16 pixels per wave the maximum runs over fewer lanes, an
+// iteration walks for fewer of them, and the waves that would have idled hold the other halves.  `in_flight`: launches that share the
+// chip (the sub-parts of prt_api.cpp).  6 144 slots = 256 CUs x 4 SIMDs x 6 waves.
+static inline unsigned launch_sub_shift(const LaunchOpts& lo, unsigned grid, unsigned in_flight) {
+    if (lo.pix_per_wave == 64) return 0u;
+    if (lo.pix_per_wave == 32) return 1u;
+    if (lo.pix_per_wave == 16) return 2u;
+    // Measured (tools/shard_time.py, one rank's share of the 1080p frame split 8 / 4 / 2 ways, 256 spp): 64 pixels per wave 0.091 / 0.117 /
+    // 0.175 s, 32: 0.111 / 0.174 / 0.256 s, 16: 0.158 / 0.267 / 0.418 s -- the chain of a wave's slowest pixel does not get shorter with
+    // fewer neighbours (an iteration issues the same instructions whoever takes part), and the extra waves cost issue slots the chip
+    // does not have to spare even at an eighth of the frame.  So: never by itself.
+    (void)grid; (void)in_flight;
+    return 0u;
+}
 template <unsigned MATS, bool MEDIUM, int WAVES>
 static void launch_variant_w(const DevScene& sc, const DevCamera& cam, const DevState& S, const FrameArgs& fa, float4* fb,
                              hipStream_t stream, unsigned grid, bool scatter) {
@@ -254,14 +276,21 @@ static void launch_variant_w(const DevScene& sc, const DevCamera& cam, const Dev
     if (!grid) return;
     FrameArgs fb_args = fa;
     fb_args.scatter = scatter ? 1u : 0u;
+    grid <<= fb_args.sub_shift;                                  // workgroups = waves: 2^sub_shift per tile
     // walk phases end below this many walking lanes (0 = not set by the caller): 8 (10 / 12: +-0.7 % in either wave-count build; the SDF
     // sets: 10 -3 %); 6 with a medium (8: -1 %) and for scattered pixels, whose waves hold more deep walks (512x512 coat: 6 +4 %).  Shadow rays: in a small tree 99 % end at the root and the
     // rest is shallow -- cutting one off costs its pixel a whole iteration, letting the wave finish them costs a few steps (cornell
     // +3 %); through a big mesh they are as deep as any ray and the bound pays as it does for the closest-hit walks (+14 %).
     // Through a tree beyond one XCD's L2: 20 / 12 (3840x2160 x 512 spp, 4096 frames per launch: 12 / 12 -> 3.84, 16 / 16 -> 3.93, 16 / 12 -> 3.96,
     // 20 / 12 -> 4.02 G segments/s; round 2, 512 frames per launch: 8 -> 2.46, 12 -> 2.52, 16 -> 2.51).
-    if (!fb_args.walk_min_lanes) fb_args.walk_min_lanes = sc.n_pairs > 65536u ? 20u : ((MEDIUM || scatter) ? 6u : 8u);
-    if (!fb_args.shadow_min_lanes) fb_args.shadow_min_lanes = sc.n_pairs > 65536u ? 12u : 1u;
+    // A launch that leaves wave slots empty (up to 1.5 rounds of waves in flight: one rank's share of a 1080p frame split 4 or 8 ways) lasts as
+    // long as its slowest pixel's chain of segments, and a lane that is cut off needs another iteration of its wave for the same segment: there
+    // every walk runs to its end (lock step) -- the share of 8 ranks 0.091 -> 0.077 s, of 4 ranks 0.117 -> 0.108 s, of 2 ranks 0.175 -> 0.209 s, the
+    // whole frame 0.286 -> 0.340 s (tools/shard_time.py, 256 spp).  Through a big tree the bound stays (the same sweep: +-2 %, or worse).
+    // (with fewer pixels per wave the thresholds shrink with the lanes that can walk at all)
+    const bool few_waves = sc.n_pairs <= 65536u && (unsigned long long)(grid >> fb_args.sub_shift) * (fa.tile_stride ? fa.tile_stride : 1u) <= 9216ull;
+    if (!fb_args.walk_min_lanes) fb_args.walk_min_lanes = few_waves ? 1u : max(2u, (sc.n_pairs > 65536u ? 20u : ((MEDIUM || scatter) ? 6u : 8u)) >> fb_args.sub_shift);
+    if (!fb_args.shadow_min_lanes) fb_args.shadow_min_lanes = sc.n_pairs > 65536u ? max(2u, 12u >> fb_args.sub_shift) : 1u;
     if (WAVES == PT_BIG_WAVES && (fb_args.tile_order || fb_args.tile_cost))     // (prt_render_spp asks for it through big trees only)
         hipLaunchKernelGGL((render_kernel<MATS, MEDIUM, WAVES, WAVES == PT_BIG_WAVES>), dim3(grid), dim3(PT_BLOCK), lds, stream, sc, cam, S, fb_args, fb);
     else
@@ -282,6 +311,9 @@ static RenderLaunch launch_variant(const char* name, const DevScene& sc, const D
     const int waves = lo.waves ? lo.waves : (sc.n_pairs > 65536u ? PT_BIG_WAVES : ((scatter || five) ? PT_WAVES : PT_BIG_WAVES));
     RenderLaunch r;
     r.name = name; r.scatter = scatter ? 1 : 0;
+    FrameArgs fs = fa;
+    fs.sub_shift = lo.pool ? 0u : launch_sub_shift(lo, grid, fa.tile_stride);
+    r.pix_per_wave = 64 >> fs.sub_shift;
     r.ordered = (!scatter && fa.tile_order && waves >= PT_BIG_WAVES) ? 1 : 0;
     // render_kernel_rp (pt_pool.h): the same launch -- same tiles or scattered pixels, same order -- with the deep walks on walker waves
     if (lo.pool) {
@@ -294,10 +326,10 @@ static RenderLaunch launch_variant(const char* name, const DevScene& sc, const D
     }
 #if defined(PT_DEV_ONE_VARIANT) && !defined(PT_DEV_BOTH_WAVES)
     r.waves = PT_BIG_WAVES;
-    launch_variant_w<MATS, MEDIUM, PT_BIG_WAVES>(sc, cam, S, fa, fb, stream, grid, scatter);
+    launch_variant_w<MATS, MEDIUM, PT_BIG_WAVES>(sc, cam, S, fs, fb, stream, grid, scatter);
 #else
-    if (waves >= PT_BIG_WAVES) { r.waves = PT_BIG_WAVES; launch_variant_w<MATS, MEDIUM, PT_BIG_WAVES>(sc, cam, S, fa, fb, stream, grid, scatter); }
-    else { r.waves = PT_WAVES; launch_variant_w<MATS, MEDIUM, PT_WAVES>(sc, cam, S, fa, fb, stream, grid, scatter); }
+    if (waves >= PT_BIG_WAVES) { r.waves = PT_BIG_WAVES; launch_variant_w<MATS, MEDIUM, PT_BIG_WAVES>(sc, cam, S, fs, fb, stream, grid, scatter); }
+    else { r.waves = PT_WAVES; launch_variant_w<MATS, MEDIUM, PT_WAVES>(sc, cam, S, fs, fb, stream, grid, scatter); }
 #endif
     return r;
 }

@@ -518,6 +518,39 @@ def test_ray_pool_kernel_through_the_big_tree(prt, oracle, monkeypatch):
     assert out[1][2:] == out[0][2:] and out[1][4] == W * H
 
 
+@pytest.mark.parametrize("per_wave", [32, 16])
+@pytest.mark.parametrize("scatter", [0, 1])
+def test_fewer_pixels_per_wave_match_golden(prt, oracle, per_wave, scatter):
+    """FrameArgs::sub_shift (prt_set_option "pix_per_wave"): a wave renders 32 or 16 pixels and 2 or 4 waves share a tile (or, scattered, the
+    launch's pixels) -- what launches that leave wave slots empty take by themselves (one rank's share of a frame split N ways).  Pixels are
+    independent, so this is bit-exact by construction; checked on goldens, on a ragged frame against the oracle and in samples-per-pixel
+    mode, both pixel mappings, what ran read back."""
+    tag = "%d per wave" % per_wave
+    for variant in ("cornell_mixed", "cornell_media_hg", "cornell_diffuse"):
+        ran = _golden_through(prt, oracle, variant, tag, pix_per_wave=per_wave, scatter=scatter)
+        assert tag in ran and ("pixels=scattered" if scatter else "pixels=tiles") in ran, ran
+    W2, H2, frames2 = 61, 43, 20                                  # neither a multiple of 8
+    scene, cfg, cam2, env, r = _setup(prt, "cornell_mixed", W2, H2)
+    r.set_option("pix_per_wave", per_wave)
+    r.set_option("scatter", scatter)
+    seeds = prt.seed_pairs(frames2)
+    ostate, oimg = oracle.Restatement().render(cfg, scene.desc, cam2, W2, H2, seeds, env=env)
+    r.render_frames(seeds)
+    assert tag in r.kernel_variant()
+    _assert_same(oracle, ostate, oimg, r.read_state(), r.read_framebuffer(), "%s, ragged frame, scatter=%d" % (tag, scatter))
+    r.close()
+    gs = np.load(os.path.join(GOLDEN, "cornell_diffuse_spp.npz"))
+    scene, cfg, cam, env, r = _setup(prt, "cornell_diffuse", int(gs["width"]), int(gs["height"]))
+    r.set_option("pix_per_wave", per_wave)
+    r.set_option("scatter", scatter)
+    r.set_option("frames_per_launch", 7)
+    r.render_spp(int(gs["spp"]), prt.seed_pairs(int(gs["frames"])))
+    assert tag in r.kernel_variant()
+    sstate = np.ascontiguousarray(gs["state"]).view(oracle.PATH_STATE_DTYPE).reshape(-1)
+    _assert_same(oracle, sstate, gs["image"], r.read_state(), r.read_framebuffer(), "%s, spp golden" % tag)
+    r.close()
+
+
 @pytest.mark.parametrize("waves", [5, 6])
 @pytest.mark.parametrize("scatter", [0, 1])
 @pytest.mark.parametrize("variant", ["cornell_diffuse", "cornell_media_hg", "cornell_sdf", "cornell_mixed", "cornell_coat", "cornell_roughdiel"])
@@ -681,7 +714,7 @@ def test_options_are_validated(prt):
     scene = prt.HostScene("cornell_diffuse.json")
     r = prt.Renderer(scene.config(), device=0)
     assert r.kernel_variant() == ""
-    for name, value in (("waves", 4), ("waves", 7), ("scatter", 2), ("generic", 2), ("any_dist", 2), ("tri_q", 17), ("frames_per_launch", -1), ("tile_order", 2), ("test_drop_report", 2), ("no_such_option", 1)):
+    for name, value in (("waves", 4), ("waves", 7), ("scatter", 2), ("generic", 2), ("any_dist", 2), ("tri_q", 17), ("frames_per_launch", -1), ("tile_order", 2), ("test_drop_report", 2), ("pix_per_wave", 48), ("pool", 2), ("no_such_option", 1)):
         with pytest.raises(prt.PrtError):
             r.set_option(name, value)
     r.close()
