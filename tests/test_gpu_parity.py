@@ -710,6 +710,48 @@ def test_a_launch_that_does_not_report_aborts_the_render(prt):
     r.close()
 
 
+@pytest.mark.parametrize("case", ["config2", "config3a", "config4"])
+def test_hip_agrees_with_the_reference_under_glibc_math(prt, case):
+    """Math this repository did not write, ON THE GPU PATH.  Every bit-exact test here is relative to include/prt_detmath.h (it feeds the
+    reference build's OpenCL runtime stand-in, the CPU restatement and the HIP kernels alike).  tests/golden/libm_means.npz holds BASELINE
+    configs 2 / 3a / 4 rendered by the reference's own kernel text with the GNU C library behind its scalar transcendental built-ins
+    (generator: tests/golden/make_libm_means.py; 128 x 128 pixels x 4 096 frames).  The two libraries part ways pixel by pixel at the first
+    decision an ulp flips (a path tracer is chaotic), so what must agree is the estimate: per channel, the image mean of the HIP render of
+    the same inputs within 0.1 % of the reference's and within 4.5 Monte-Carlo errors of the difference (from the spread of the 8 x 8 block
+    means: blocks decorrelate the pixels that share RNG streams)."""
+    g = np.load(os.path.join(GOLDEN, "libm_means.npz"))
+    size, frames = int(g["size"]), int(g["frames"])
+    scene_json, phase, use_env = {"config2": ("cornell_diffuse.json", 0, False), "config3a": ("cornell_roughcond.json", 0, True),
+                                  "config4": ("cornell_media.json", 1, True)}[case]
+    scene = prt.HostScene(scene_json)
+    cfg = scene.config()
+    cfg.phase_function = phase
+    r = prt.Renderer(cfg, device=0)
+    r.upload_scene(scene)
+    if use_env:
+        r.upload_envmap(prt.make_sky(64, 32))
+    r.set_camera(prt.default_camera(size, size))
+    r.resize(size, size)
+    r.render_frames(prt.seed_pairs(frames))
+    img = r.read_framebuffer().reshape(size, size, 4)[..., :3].astype(np.float64)
+    assert r.counts(0).segments == int(g[case + "_segments"])          # (one segment per pixel and frame, whatever the math)
+    r.close()
+    ok = np.isfinite(img).all(axis=2)
+    a = np.where(ok[..., None], img, 0.0)
+    h = size // 8
+    cnt = ok.reshape(h, 8, h, 8).sum(axis=(1, 3))
+    mine = a.reshape(h, 8, h, 8, 3).sum(axis=(1, 3)) / np.maximum(cnt, 1)[..., None]
+    ref, ref_cnt = g[case + "_blocks"], g[case + "_counts"]
+    use = (cnt >= 16) & (ref_cnt >= 16)                                 # blocks with enough finite pixels in both renders
+    assert use.mean() > 0.9, use.mean()
+    for ch in range(3):
+        m_hip, m_ref = mine[..., ch][use].mean(), ref[..., ch][use].mean()
+        d = (mine[..., ch] - ref[..., ch])[use]
+        sigma = d.std(ddof=1) / np.sqrt(d.size)
+        z = (m_hip - m_ref) / sigma
+        assert abs(m_hip / m_ref - 1.0) < 1e-3 and abs(z) < 4.5, (case, "RGB"[ch], m_hip, m_ref, m_hip / m_ref, z)
+
+
 def test_options_are_validated(prt):
     scene = prt.HostScene("cornell_diffuse.json")
     r = prt.Renderer(scene.config(), device=0)

@@ -5,8 +5,8 @@ Builds oracle/pt_oracle.c (the line-by-line cited restatement, bit-identical to 
 with gcov instrumentation, replays exactly the inputs of the golden fixtures (tests/golden/*.npz: same scenes, cameras,
 sizes, frame counts, seeds -- and checks it reproduces them), and prints the source lines of pt_oracle.c that were never
 executed together with the function they belong to (every function cites the reference file:line it restates).
-The committed report is profiles/r02_oracle_coverage.txt.
-usage: python tools/oracle_coverage.py > profiles/r02_oracle_coverage.txt"""
+The committed report is profiles/r04_oracle_coverage.txt (round 2's: r02_).
+usage: python tools/oracle_coverage.py > profiles/r04_oracle_coverage.txt"""
 import ctypes as C
 import importlib
 import os
@@ -70,7 +70,7 @@ def replay(so):
     """renders every golden fixture's input with the instrumented oracle; the counters are written when this process exits"""
     prt = importlib.import_module("photorealistic-rendering-using-opencl_amd")
     import oracle_api as O
-    from conftest import ALPHA_VARIANTS, GOLDEN, VARIANTS, variant_camera
+    from conftest import GOLDEN, VARIANTS, variant_camera, variant_config
     rs = O.Restatement(so)
     replayed = []
     for name, (scene_json, phase, use_env) in VARIANTS.items():
@@ -78,7 +78,7 @@ def replay(so):
         g = np.load(gpath) if os.path.exists(gpath) else None
         W, H, frames = (int(g["width"]), int(g["height"]), int(g["frames"])) if g is not None else (int(os.environ.get("COV_W", 48)), int(os.environ.get("COV_H", 36)), int(os.environ.get("COV_FRAMES", 256)))
         scene = prt.HostScene(scene_json)
-        cfg = scene.config(alpha_testing=name in ALPHA_VARIANTS)
+        cfg = variant_config(scene, name)                      # (-alpha, PICK_RANDOM_LIGHT: what the reference build of the fixture was given)
         cfg.phase_function = phase
         cam = variant_camera(prt, name, W, H)
         env = prt.make_sky(64, 32) if use_env else None
@@ -87,6 +87,19 @@ def replay(so):
             gstate = np.ascontiguousarray(g["state"]).view(O.PATH_STATE_DTYPE).reshape(-1)
             assert not O.state_fields_equal(gstate, state) and O.images_equal(g["image"], img), name
         replayed.append("%s %dx%dx%d%s" % (name, W, H, frames, "" if g is not None else " (no golden yet)"))
+    from conftest import VIEW_VARIANTS
+    for fixture, (base, view) in VIEW_VARIANTS.items():      # the debug views of main.cl:6-15 (prt_config::view_option)
+        g = np.load(os.path.join(GOLDEN, fixture + ".npz"))
+        scene_json, phase, use_env = VARIANTS[base]
+        W, H, frames = int(g["width"]), int(g["height"]), int(g["frames"])
+        scene = prt.HostScene(scene_json)
+        cfg = variant_config(scene, base)
+        cfg.phase_function = phase
+        cfg.view_option = view
+        state, img = rs.render(cfg, scene.desc, variant_camera(prt, base, W, H), W, H, prt.seed_pairs(frames), env=prt.make_sky(64, 32) if use_env else None, threads=4)
+        gstate = np.ascontiguousarray(g["state"]).view(O.PATH_STATE_DTYPE).reshape(-1)
+        assert not O.state_fields_equal(gstate, state) and O.images_equal(g["image"], img), fixture
+        replayed.append("%s %dx%dx%d" % (fixture, W, H, frames))
     g = np.load(os.path.join(GOLDEN, "cornell_diffuse_spp.npz"))
     scene = prt.HostScene("cornell_diffuse.json")
     rs.render(scene.config(), scene.desc, prt.default_camera(int(g["width"]), int(g["height"])), int(g["width"]), int(g["height"]),

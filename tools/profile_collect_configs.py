@@ -37,10 +37,12 @@ for cfg in ("c1", "c3a", "c3b", "c4"):
     rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
     k = rows[0]
     rl = line["roofline"]
-    frac = 240.0 * line["config"]["segments_per_step"] * line["steps"] / (float(k["TotalDurationNs"]) * 1e-9 / rl["concurrent_launches"]) / 8e12
+    # per launch: the stats file also holds the launches of the warm-up steps, the bench line's counts are those of the timed ones
+    launches_per_step = rl["launches"] / float(line["steps"])
+    frac = 240.0 * line["config"]["segments_per_step"] / (launches_per_step * float(k["AverageNs"]) * 1e-9 / rl["concurrent_launches"]) / 8e12
     out = {"config": cfg, "workload": line["config"]["workload"], "bench_line_of_the_profiled_run": line, "counters_at_128spp": c, "derived": d,
            "dominant_kernel": {"name": k["Name"][:90], "calls": int(k["Calls"]), "average_ns": float(k["AverageNs"]), "total_ns": float(k["TotalDurationNs"]), "percent": float(k["Percentage"])},
-           "frac_recomputed = 240 B x segments / (kernel total / concurrent launches) / 8 TB/s": frac}
+           "frac_recomputed = 240 B x segments per step / (launches per step x average launch time / concurrent launches) / 8 TB/s": frac}
     with open(os.path.join(dst, tag + "pmc_%s.json" % cfg), "w") as f:
         json.dump(out, f, indent=1)
         f.write("\n")
