@@ -23,7 +23,7 @@ SCENES_DIR = os.path.join(REPO, "scenes")
 MODELS_DIR = os.path.join(SCENES_DIR, "models")
 
 __all__ = ["ensure_dragon_standin", "HostScene", "Renderer", "default_camera", "orbit_camera", "seed_pairs", "make_sky", "load_hdr", "write_hdr", "PrtError",
-           "Camera", "Config", "SceneDesc", "Stats", "PATH_STATE_DTYPE", "SCENES_DIR", "MODELS_DIR", "build", "build_id", "source_build_id", "check_build_id", "StaleLibrary"]
+           "Camera", "Config", "SceneDesc", "Stats", "PATH_STATE_DTYPE", "SCENES_DIR", "MODELS_DIR", "build", "model_meshes", "build_id", "source_build_id", "check_build_id", "StaleLibrary"]
 
 
 class PrtError(RuntimeError):
@@ -72,6 +72,17 @@ def check_build_id():
         raise StaleLibrary("libprt.so was built from other sources than the working tree holds (library %s, tree %s): "
                            "rebuild with `python __graft_entry__.py build`" % (have, want))
     return have
+
+
+def model_meshes(path, max_meshes=64):
+    """[(triangles, welded vertices, de-indexing gives the soup back)] per mesh of a model file (csrc/host/model_loader.h)"""
+    lib = load_library()
+    counts = (C.c_uint32 * (3 * max_meshes))()
+    err = C.create_string_buffer(512)
+    n = lib.prth_model_meshes(path.encode(), counts, max_meshes, err, 512)
+    if n < 0:
+        raise PrtError("model load failed: %s" % err.value.decode(), n)
+    return [(counts[3 * m], counts[3 * m + 1], bool(counts[3 * m + 2])) for m in range(min(n, max_meshes))]
 
 
 def ensure_dragon_standin():

@@ -115,6 +115,7 @@ PRTH_API = [
                                     C.c_float, C.POINTER(Camera)]),
     ("prth_seed_pairs", C.c_int, [C.c_uint32, C.c_uint32, C.c_void_p]),
     ("prth_convert_model", C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]),
+    ("prth_model_meshes", C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_char_p, C.c_int]),
     ("prth_make_sky", C.c_int, [C.c_int, C.c_int, C.c_void_p]),
     ("prth_hdr_load", C.c_void_p, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_float)), C.c_char_p, C.c_int]),
     ("prth_hdr_free", None, [C.c_void_p]),

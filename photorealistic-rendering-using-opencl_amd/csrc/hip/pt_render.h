@@ -307,7 +307,11 @@ static RenderLaunch launch_variant(const char* name, const DevScene& sc, const D
     // of scratch) and the generic dispatch (112 instead of 208 B) -- and for scattered pixels of a small tree (one or two rounds of waves,
     // every wave at its own latency: 512x512 coat +5 %).  Measured at 1080p, 5 against 6 waves: LIGHT|DIFF -6 %, rough conductor -3.6 %,
     // rough dielectric -2.3 %, coat +-0 ... +1.3 %, generic +-0; with a medium -7 %, SDF -15 %.
-    constexpr bool five = !MEDIUM && !(MATS & PT_MATS_SDF) && ((MATS & ~PT_MATS_FLAGS) == 0u || (MATS & PRT_MAT_COAT) != 0u);
+    // Round 4, the sets outside the BASELINE configs (same call, twice each, 1080p): generic dispatch 5 against 6 waves +8 % (cornell_mixed;
+    // 84 instead of 180 B of scratch), generic with a medium +3 % (132 / 200 B), coat +1 %, the raymarched SDF set -8 % (116 / 172 ... 256 B:
+    // the raymarcher's latency wants the sixth wave more than its spills cost) -- so the run-time dispatch runs its 96-register build with or
+    // without a medium (and with it the debug-view, light-pick and environment-sampling sets, which are that dispatch plus a flag), SDF its 80.
+    constexpr bool five = !(MATS & PT_MATS_SDF) && ((MATS & ~PT_MATS_FLAGS) == 0u || (!MEDIUM && (MATS & PRT_MAT_COAT) != 0u));
     const int waves = lo.waves ? lo.waves : (sc.n_pairs > 65536u ? PT_BIG_WAVES : ((scatter || five) ? PT_WAVES : PT_BIG_WAVES));
     RenderLaunch r;
     r.name = name; r.scatter = scatter ? 1 : 0;

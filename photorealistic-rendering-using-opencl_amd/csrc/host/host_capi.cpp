@@ -124,6 +124,28 @@ extern "C" int prth_convert_model(const char* in_path, const char* out_path, cha
     return PRT_OK;
 }
 
+// meshes of a model file and, per mesh, its triangles and the vertices left after welding (prt::IO::ModelLoader::weld): counts[3 * m + {0, 1, 2}]
+extern "C" int prth_model_meshes(const char* path, uint32_t* counts, int max_meshes, char* err, int err_len) {
+    prt::IO::ModelLoader ml;
+    if (!path || !ml.ImportFromFile(path)) { set_err(err, err_len, path ? ml.last_error() : std::string("null argument")); return PRT_ERR_INVALID_ARGUMENT; }
+    const auto& meshes = ml.getFaces().meshes;
+    for (size_t m = 0; m < meshes.size() && (int)m < max_meshes && counts; ++m) {
+        std::vector<prt::IO::Vertex> v;
+        std::vector<uint32_t> idx;
+        ml.weld(m, v, idx);
+        bool same = idx.size() == 3 * meshes[m].faces.size();          // de-indexing must give the soup back
+        for (size_t k = 0; same && k < idx.size(); ++k) {
+            const prt::IO::Vertex& a = v[idx[k]];
+            const prt::IO::Vertex& b = meshes[m].faces[k / 3].points[k % 3];
+            same = a.pos.x == b.pos.x && a.pos.y == b.pos.y && a.pos.z == b.pos.z && a.nor.x == b.nor.x && a.nor.y == b.nor.y && a.nor.z == b.nor.z;
+        }
+        counts[3 * m] = (uint32_t)meshes[m].faces.size();
+        counts[3 * m + 1] = (uint32_t)v.size();
+        counts[3 * m + 2] = same ? 1u : 0u;
+    }
+    return (int)meshes.size();
+}
+
 extern "C" void* prth_hdr_load(const char* path, int* width, int* height, const float** rgb, char* err, int err_len) {
     auto* v = new std::vector<float>();
     std::string e;

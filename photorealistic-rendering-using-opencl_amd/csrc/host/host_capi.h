@@ -38,6 +38,12 @@ int prth_seed_pairs(uint32_t first_frame, uint32_t n_frames, int32_t* out_pairs)
 /* OBJ -> ".prtmesh" soup conversion (tools / fixtures) */
 int prth_convert_model(const char* in_path, const char* out_soup_path, char* err, int err_len);
 
+/* the meshes of a model file (an OBJ file's objects / groups / materials, in file order: src/Models/model_loader.cpp:58-74 walks them all):
+ * returns their number (negative: error) and fills, per mesh m < max_meshes, counts[3m] = triangles, counts[3m + 1] = vertices left after
+ * welding identical (position, normal) pairs (aiProcess_JoinIdenticalVertices of the reference's import preset, model_loader.cpp:38),
+ * counts[3m + 2] = 1 if de-indexing the welded mesh gives the soup back float for float */
+int prth_model_meshes(const char* path, uint32_t* counts, int max_meshes, char* err, int err_len);
+
 /* deterministic procedural sky used as the HDR environment stand-in (no .hdr ships with the
  * reference): width x height RGB float, row 0 = top (v = 0) */
 int prth_make_sky(int width, int height, float* rgb);

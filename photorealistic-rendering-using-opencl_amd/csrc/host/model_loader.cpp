@@ -84,10 +84,23 @@ bool ModelLoader::load_obj(const std::string& path) {
     std::vector<size_t> needs_normals;          // faces whose corners came without a vn record
     std::string line;
     struct Corner { long v, n; };
+    // A file with several objects / groups / materials is several MESHES: assimp's OBJ importer opens a new mesh at every `o`, `g` (it maps
+    // groups onto objects) and `usemtl` that is followed by faces, and the reference walks them all in that order
+    // (src/Models/model_loader.cpp:58-74, updateSceneData) -- the soup is their concatenation, in file order.  What the split changes is
+    // GenSmoothNormals, which works mesh by mesh: corners of two groups that share a position do not share a normal.
+    auto flush = [&]() {
+        if (mesh.faces.empty()) return;
+        smooth_missing_normals(mesh, needs_normals);       // faces without vn records, within this mesh only
+        scene_.meshes.push_back(std::move(mesh));
+        mesh = Mesh();
+        needs_normals.clear();
+    };
     while (std::getline(f, line)) {
         const char* s = line.c_str();
         while (*s == ' ' || *s == '\t') ++s;
-        if (s[0] == 'v' && (s[1] == ' ' || s[1] == '\t')) {
+        if (((s[0] == 'o' || s[0] == 'g') && (s[1] == ' ' || s[1] == '\t' || s[1] == '\r' || s[1] == 0)) || std::strncmp(s, "usemtl", 6) == 0) {
+            flush();
+        } else if (s[0] == 'v' && (s[1] == ' ' || s[1] == '\t')) {
             float3 p; char* e;
             p.x = strtof(s + 2, &e); p.y = strtof(e, &e); p.z = strtof(e, &e);
             // strtof accepts "nan" / "inf": a non-finite position would make the BVH builder's ordering undefined
@@ -142,10 +155,30 @@ bool ModelLoader::load_obj(const std::string& path) {
             }
         }
     }
-    if (mesh.faces.empty()) { err_ = "no faces in '" + path + "'"; return false; }
-    smooth_missing_normals(mesh, needs_normals);           // files without vn records
-    scene_.meshes.push_back(std::move(mesh));
+    flush();
+    if (scene_.meshes.empty()) { err_ = "no faces in '" + path + "'"; return false; }
     return true;
+}
+
+// aiProcess_JoinIdenticalVertices (part of the preset of src/Models/model_loader.cpp:38): vertices of a mesh that agree in every
+// attribute become one, the faces index them.  On the render path nothing can see it -- the renderer de-indexes every mesh again
+// (src/main.cpp:93-119) -- so the soup above is what ships; this is the indexed view for callers that want assimp's (exporters, a
+// builder that shares vertices).  Identity is bit identity of (position, normal) with -0 == +0, first occurrence first: de-indexing
+// gives the soup back float for float.
+void ModelLoader::weld(size_t mesh_index, std::vector<Vertex>& vertices, std::vector<uint32_t>& indices) const {
+    vertices.clear(); indices.clear();
+    if (mesh_index >= scene_.meshes.size()) return;
+    struct Key { uint32_t w[6]; bool operator<(const Key& o) const { return std::memcmp(w, o.w, sizeof(w)) < 0; } };
+    std::map<Key, uint32_t> seen;
+    for (const Face& face : scene_.meshes[mesh_index].faces)
+        for (const Vertex& v : face.points) {
+            const float c[6] = {v.pos.x + 0.0f, v.pos.y + 0.0f, v.pos.z + 0.0f, v.nor.x + 0.0f, v.nor.y + 0.0f, v.nor.z + 0.0f};
+            Key k;
+            std::memcpy(k.w, c, sizeof(c));
+            auto it = seen.find(k);
+            if (it == seen.end()) { it = seen.emplace(k, (uint32_t)vertices.size()).first; vertices.push_back(v); }
+            indices.push_back(it->second);
+        }
 }
 
 // ---- Stanford PLY (ascii 1.0 / binary_little_endian 1.0): element vertex {x y z [nx ny nz] ...}, element face {list <count> <index>

@@ -2,10 +2,13 @@
 // view (include/Model/model_loader.h:21-62).  The reference imports through assimp
 // (src/Models/model_loader.cpp:38), which is not available; this loader reads Wavefront OBJ
 // (v / vn / f, fan-triangulated polygons, negative indices), Stanford PLY (ascii / binary little-endian), STL (ascii / binary) and
-// the ".prtmesh" binary soup ("PRTMESH1", uint32 triangle_count, then per triangle 3 x {pos xyz, nor xyz} float32).  All meshes /
-// groups of a file are flattened into one triangle list, as ModelLoader::getFaces' only user does (src/main.cpp:93-119).
+// the ".prtmesh" binary soup ("PRTMESH1", uint32 triangle_count, then per triangle 3 x {pos xyz, nor xyz} float32).  An OBJ file with
+// several objects / groups / materials gives several meshes, in file order, as assimp's importer does (normals that have to be generated
+// are smoothed within a mesh); every consumer walks all meshes (src/Models/model_loader.cpp:58-74, src/main.cpp:93-119), so the soup is
+// their concatenation.
 #pragma once
 #include <array>
+#include <cstdint>
 #include <memory>
 #include <string>
 #include <vector>
@@ -30,6 +33,8 @@ public:
     // flattened buffers exactly as src/main.cpp:93-119 uploads them: float4 per corner (w = 0)
     void flatten(std::vector<float>& vertices4, std::vector<float>& normals4) const;
     bool SaveSoup(const std::string& filepath) const;
+    // the indexed view of one mesh (aiProcess_JoinIdenticalVertices): unique (position, normal) vertices in order of first use + 3 indices per face
+    void weld(size_t mesh_index, std::vector<Vertex>& vertices, std::vector<uint32_t>& indices) const;
 
 private:
     bool load_obj(const std::string& path);

@@ -309,3 +309,43 @@ def test_hostile_inputs_are_refused_before_they_cost_memory(prt, tmp_path):
     nan_soup.write_bytes(b"PRTMESH1" + struct.pack("<I", 1) + np.array([0, 0, 0, 0, 0, 1, 1, np.nan, 0, 0, 0, 1, 1, 1, 0, 0, 0, 1], dtype=np.float32).tobytes())
     with pytest.raises(prt.PrtError, match="non-finite"):
         prt.HostScene(text.replace("lie.prtmesh", "nan.prtmesh"), models_dir=str(tmp_path), text=True)
+
+
+def test_obj_groups_are_meshes_and_welding_gives_the_soup_back(prt, tmp_path):
+    """N2: (a) an OBJ file with several objects / groups / materials is several meshes, in file order -- what assimp's importer makes of
+    it and what the reference walks (src/Models/model_loader.cpp:58-74); the soup is their concatenation, and normals that have to be
+    GENERATED are smoothed within a mesh only (GenSmoothNormals works mesh by mesh), so two groups that share an edge keep a crease;
+    (b) aiProcess_JoinIdenticalVertices (model_loader.cpp:38) as the loader's `weld` view: unique (position, normal) vertices + indices,
+    de-indexing gives the soup back float for float (on the render path nothing can see welding: src/main.cpp:93-119 de-indexes).
+    There is no oracle (assimp is an absent submodule): the pin is the OBJ reader on the same geometry."""
+    # two triangles sharing the edge (0,0,0)-(0,1,0), folded by 90 degrees
+    verts = "v 0 0 0\nv 0 1 0\nv 1 0 0\nv 0 0 1\n"
+    one = tmp_path / "one.obj"
+    one.write_text(verts + "f 1 3 2\nf 1 2 4\n")
+    two = tmp_path / "two.obj"
+    two.write_text(verts + "o left\nf 1 3 2\ng right\nusemtl red\nf 1 2 4\n")
+    assert [m[0] for m in prt.model_meshes(str(one))] == [2]
+    assert [m[0] for m in prt.model_meshes(str(two))] == [1, 1]
+    a, b = _soup(prt, one, tmp_path), _soup(prt, two, tmp_path)
+    assert a.shape == b.shape == (2, 3, 6)
+    assert np.array_equal(a[:, :, :3], b[:, :, :3])                       # same triangles, same order
+    # one mesh: the corners on the shared edge carry the normalised sum of both face normals; two meshes: each face its own
+    fa = np.cross(a[0, 1, :3] - a[0, 0, :3], a[0, 2, :3] - a[0, 0, :3]); fa /= np.linalg.norm(fa)
+    fb = np.cross(a[1, 1, :3] - a[1, 0, :3], a[1, 2, :3] - a[1, 0, :3]); fb /= np.linalg.norm(fb)
+    avg = (fa + fb) / np.linalg.norm(fa + fb)
+    assert np.allclose(a[0, 0, 3:], avg, atol=1e-6) and np.allclose(a[1, 0, 3:], avg, atol=1e-6)     # corner (0,0,0): smoothed across
+    assert np.allclose(a[0, 1, 3:], fa, atol=1e-6)                                                    # corner (1,0,0): one face only
+    assert np.allclose(b[0, :, 3:], np.tile(fa, (3, 1)), atol=1e-6) and np.allclose(b[1, :, 3:], np.tile(fb, (3, 1)), atol=1e-6)
+    # welding: the shared corners of `one` are one vertex each (4 vertices for 6 corners), of `two` nothing is shared across meshes
+    assert prt.model_meshes(str(one)) == [(2, 4, True)]
+    assert prt.model_meshes(str(two)) == [(1, 3, True), (1, 3, True)]
+    # the teapot of the reference's own scene: 6 320 triangles, every corner with a vn record; welded to a fraction, and back
+    teapot = prt.model_meshes(os.path.join(prt.MODELS_DIR, "teapot.obj"))
+    assert sum(m[0] for m in teapot) == 6320 and all(m[2] for m in teapot)
+    assert sum(m[1] for m in teapot) < 6320 * 3 // 4
+    # a renderer that is given the two-mesh file sees ONE soup (BVH over all meshes): same triangle count as the one-mesh file
+    for path in (one, two):
+        scene = prt.HostScene('{"scene": {"obj": {"path": "%s", "material": {"color": [1, 1, 1], "type": 1}}, "camera": {}, "objects": ['
+                              '{"type": 1, "position": [0, 3, 0], "radius": 0.5, "material": {"color": [5, 5, 5], "type": 0}}]}}' % path.name,
+                              models_dir=str(tmp_path), text=True)
+        assert scene.desc.triangle_count == 2
