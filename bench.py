@@ -38,7 +38,7 @@ The JSON line also carries
                 registers for the 512 frames of a launch, so the measured traffic is ~2 % of the
                 algorithmic bytes: HBM is the bound SURVEY s8d prescribes for the accounting, not what
                 binds.  What does is in `valu`: vector instructions per wave-segment and lane occupancy
-                (PMC passes of the same workload, profiles/r03_pmc_render_kernel.json) and, from this
+                (PMC passes of the same workload, profiles/r04_pmc_render_kernel.json) and, from this
                 run's segment rate, the share of the chip's vector issue slots they take.
   cpu_baseline  oracle/pt_oracle.c (a scalar-per-pixel CPU port, multi-threaded over pixels) on a
                 bounded sample of the same workload, rank 0, N = 1 only.
@@ -248,7 +248,7 @@ def main():
         # rank-0 kernel: its own segments per step over its own kernel time
         achieved = ALGO_BYTES_PER_SEGMENT * own_segments * steps / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         traffic = None
-        for tname in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+        for tname in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if traffic is None and os.path.exists(tpath):
                 try:
@@ -260,7 +260,9 @@ def main():
         avg_launch_ms = kernel_sum_ms / max(launches, 1)
         gseg = own_segments * steps / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         valu = None
-        ppath = os.path.join(ROOT, "profiles", "r03_pmc_render_kernel.json")
+        ppath = os.path.join(ROOT, "profiles", "r04_pmc_render_kernel.json")
+        if not os.path.exists(ppath):
+            ppath = os.path.join(ROOT, "profiles", "r03_pmc_render_kernel.json")
         if world == 1 and os.path.exists(ppath):
             try:
                 pj = json.load(open(ppath))
@@ -273,7 +275,7 @@ def main():
                             "lane_occupancy": round(d["lane_occupancy = SQ_THREAD_CYCLES_VALU/(64*SQ_ACTIVE_INST_VALU)"], 4),
                             "wait_fraction": round(d["wait_fraction = SQ_WAIT_ANY/SQ_WAVE_CYCLES"], 4),
                             "issue_frac": round(vws * (gseg * 1e9 / 64.0) / issue_peak, 4),
-                            "source": "profiles/r03_pmc_render_kernel.json (rocprofv3 --pmc passes of this workload at %s spp); issue_frac = "
+                            "source": "profiles/" + os.path.basename(ppath) + " (rocprofv3 --pmc passes of this workload at %s spp); issue_frac = "
                                       "valu_per_wave_segment x this run's wave-segments/s / (1024 SIMDs x 2.4 GHz / 2)" % pj.get("spp", "?")}
             except Exception:
                 valu = None
