@@ -11,8 +11,13 @@
 //     allocate) and waits for the answer {t, u, v, slot, found} with its context where it is, as a cut-off lane does in render_kernel;
 //   * a walker wave does nothing but walk: its idle lanes take posted rays from the pool (whenever a quarter of them are idle: the
 //     persistent while-while scheme), run bvh.cl's traversal with the same walk_begin / walk_box / walk_tri (same boxes, same order,
-//     same triangle rule), write the answer into the slot and mark it done.  Rays of five waves fill the walker's lanes where one
-//     wave's own deep rays filled a sixth of them.
+//     same triangle rule), write the answer into the slot and mark it done.  Rays of several waves fill the walker's lanes (24 - 42 of
+//     64, measured) where one wave's own deep rays filled a sixth of them.
+//
+// MEASURED SLOWER than render_kernel on every workload (DESIGN.md s4 "Round 4", profiles/r04_regrouping_experiments.txt: 9.85 against 13.1 G
+// segments/s on the headline config with 3 + 1 waves, 2.06 against 3.75 through the 871 k-triangle mesh): a posted ray is away for the latency
+// of its chain of dependent loads while the shading iteration, rid of its walk loops, got three times shorter -- a third of the shading lanes
+// wait.  Off by default (prt_set_option "pool"); kept, tested, as the measured answer to "why not walker waves".
 //
 // Results cannot depend on any of this: the walk of a ray is the same function whoever runs it (tests/test_gpu_parity.py renders the
 // goldens through this kernel: prt_set_option "pool").
