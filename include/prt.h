@@ -200,6 +200,9 @@ int prt_set_walk_min_lanes(prt_ctx* ctx, uint32_t lanes);
  *                               lanes have one pending (default 4)
  *   "frames_per_launch" >= 0    frames one launch of the render kernel covers (0 = default: 512, or 4096 through a tree of more than 64 k node pairs)
  *   "run_ahead"         0 | 1   prt_render_spp: see there
+ *   "pace"              1 | 0   prt_render_spp: a pixel whose paths are longer than the frame's average owes every launch proportionally more frames
+ *                               (it needs proportionally more for its samples; what it does not do while the chip is full it does in the tail of the
+ *                               render, alone); 0: every pixel owes a launch the same number of frames
  *   "tile_order"        1 | 0   prt_render_spp starts the tiles whose waves ran longest in a sub-part's first launch first in its later
  *                               launches (and renders, until scene, camera or frame change; setting the option to the value it has
  *                               keeps a measured order); 0: in index order

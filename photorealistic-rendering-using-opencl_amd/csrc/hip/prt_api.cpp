@@ -72,6 +72,9 @@ struct prt_ctx {
     // the pending triangle tests of a walk phase run once this many sixteenths of its walking lanes have one (PRT_TRI_Q; render_kernel)
     uint32_t tri_sixteenths = 4;
     uint32_t run_ahead = 1;                        // FrameArgs::run_ahead of prt_render_spp's launches (PRT_RUN_AHEAD=0: off)
+    // prt_render_spp: pixels whose paths are longer than the frame's average owe every launch proportionally more frames (FrameArgs::pace_inv_ref;
+    // PRT_PACE=0 / option "pace": off).  The frame's mean path length is taken once per render, after the first launch that retires.
+    int pace = 1;
     // Expensive tiles first (prt_render_spp through trees of more than 64 k node pairs, FrameArgs::tile_order): the waves of launch 0 of
     // each sub-part leave what their tile cost (iterations),
     // the host sorts, and from launch 1 on -- and in later renders, until scene, camera or frame change -- the sub-part's workgroups take
@@ -147,6 +150,7 @@ extern "C" int prt_create(int device, const prt_config* cfg, prt_ctx** out) {
     c->stream = c->own_stream;
     if (const char* ev = std::getenv("PRT_FRAMES_PER_LAUNCH")) { const int k = std::atoi(ev); if (k >= 1) c->frames_per_launch = (unsigned)k; }
     if (const char* ev = std::getenv("PRT_RUN_AHEAD")) c->run_ahead = std::atoi(ev) != 0 ? 1u : 0u;
+    if (const char* ev = std::getenv("PRT_PACE")) c->pace = std::atoi(ev) != 0 ? 1 : 0;
     if (const char* ev = std::getenv("PRT_WALK_MIN_LANES")) { const int k = std::atoi(ev); if (k >= 1 && k <= 64) c->walk_min_lanes = (uint32_t)k; }
     if (const char* ev = std::getenv("PRT_WAVES")) { const int k = std::atoi(ev); if (k == 5 || k == 6) c->lo.waves = k; }
     if (const char* ev = std::getenv("PRT_SCATTER")) { const int k = std::atoi(ev); if (k == 0 || k == 1) c->lo.scatter = k; }
@@ -387,7 +391,7 @@ static FrameArgs frame_args(prt_ctx* c, uint32_t first_frame, uint32_t n, const 
     fa.width = c->width; fa.full_height = c->full_height; fa.row0 = c->row0; fa.rows = c->rows;
     fa.block_rows = c->block_rows; fa.n_parts = c->n_parts; fa.part = c->part;
     fa.first_frame = first_frame; fa.n_frames = n; fa.seed_pairs = d_seeds; fa.spp_limit = spp;
-    fa.seed_frames = n; fa.run_ahead = 0;
+    fa.seed_frames = n; fa.run_ahead = 0; fa.pace_inv_ref = 0.0f;
     fa.unfinished = count ? c->d_counters : nullptr;
     fa.unfinished_host = nullptr;
     fa.tile_first = 0; fa.tile_stride = 1; fa.scatter = 0; fa.sub_shift = 0;
@@ -398,6 +402,17 @@ static FrameArgs frame_args(prt_ctx* c, uint32_t first_frame, uint32_t n, const 
     fa.shadow_min_lanes = c->shadow_min_lanes;
     fa.tri_sixteenths = c->tri_sixteenths;
     return fa;
+}
+
+// 1 / (mean path length of the frame so far) = paths started / segments executed over all pixels (one small reduction over the state planes on
+// `stream`, which must be idle); 0 if nothing has been rendered yet
+static float inverse_mean_path_length(prt_ctx* c, uint32_t spp, hipStream_t stream) {
+    unsigned long long h[3] = {0, 0, 0};
+    if (hipMemsetAsync(c->d_counters + 1, 0, 3 * sizeof(unsigned long long), stream) != hipSuccess) return 0.0f;
+    launch_count(c->S, c->npix, spp, c->d_counters + 1, stream);
+    if (hipMemcpyAsync(h, c->d_counters + 1, sizeof(h), hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) return 0.0f;
+    static const double k = [] { const char* e = std::getenv("PRT_PACE_K"); const double v = e ? std::atof(e) : 0.0; return v > 0.0 ? v : 1.0; }();   // (experiments)
+    return (h[0] && h[1]) ? (float)(k * (double)h[0] / (double)h[1]) : 0.0f;
 }
 
 // sub-parts the megakernel renders this frame part in (1 = one launch covers every tile)
@@ -473,17 +488,20 @@ extern "C" int prt_render_spp(prt_ctx* c, uint32_t spp, uint32_t max_frames, con
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     uint32_t f = 0;
     unsigned long long unfinished = 1;
+    float pace_inv_ref = 0.0f;                     // 1 / (the frame's mean path length): known once the first launch has retired
     if (K == 1) {
         while (f < max_frames && unfinished) {
             const uint32_t n = (max_frames - f < step) ? max_frames - f : step;
             HIPCHK(c, hipMemsetAsync(c->d_counters, 0, sizeof(unsigned long long), c->stream));
             FrameArgs fa = frame_args(c, 1 + f, n, c->d_seeds + 2 * (size_t)f, spp, true);
             fa.seed_frames = max_frames - f; fa.run_ahead = c->run_ahead;
+            fa.pace_inv_ref = (c->pace && c->run_ahead) ? pace_inv_ref : 0.0f;
             c->last = launch_render(c->sc, c->cam, c->S, fa, c->fb, c->stream, c->lo);
             ++c->stats.launches;
             f += n;
             HIPCHK(c, hipMemcpyAsync(&unfinished, c->d_counters, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (c->pace && c->run_ahead && pace_inv_ref == 0.0f && unfinished) pace_inv_ref = inverse_mean_path_length(c, spp, c->stream);
         }
     } else {
         // Every sub-part advances on its own stream until its own pixels are frozen.  The last wave of a launch writes
@@ -524,6 +542,7 @@ extern "C" int prt_render_spp(prt_ctx* c, uint32_t spp, uint32_t max_frames, con
                     const uint32_t n = (max_frames - fj[j] < step) ? max_frames - fj[j] : step;
                     FrameArgs fa = frame_args(c, 1 + fj[j], n, c->d_seeds + 2 * (size_t)fj[j], spp, true);
                     fa.seed_frames = max_frames - fj[j]; fa.run_ahead = c->run_ahead;
+                    fa.pace_inv_ref = (c->pace && c->run_ahead) ? pace_inv_ref : 0.0f;
                     fa.unfinished = c->d_counters + 4 + 2 * j;
                     fa.unfinished_host = c->h_unfinished + 2 * j + slot;
                     if (c->test_drop_report) fa.unfinished_host = c->h_unfinished + 2 * prt_ctx::MAX_SUB;     // (tests: the report goes astray)
@@ -570,6 +589,8 @@ extern "C" int prt_render_spp(prt_ctx* c, uint32_t spp, uint32_t max_frames, con
                         SUBCHK(hipStreamSynchronize(c->sub_stream[j]));      // (the host vector is reused by the other sub-part)
                         c->have_order[j] = true;
                     }
+                    // the frame's mean path length, once per render (this sub-part's stream is idle: its launch has just retired)
+                    if (c->pace && c->run_ahead && pace_inv_ref == 0.0f && left) pace_inv_ref = inverse_mean_path_length(c, spp, c->sub_stream[j]);
                     ++retired[j];
                     progressed = true;
                     if (!stop[j]) {
@@ -624,6 +645,7 @@ extern "C" int prt_set_option(prt_ctx* c, const char* name, int value) {
     else if (n == "tri_q") { if (value < 0 || value > 16) return bad(); c->tri_sixteenths = (uint32_t)value; }
     else if (n == "frames_per_launch") { if (value < 0) return bad(); c->frames_per_launch = (unsigned)value; }
     else if (n == "run_ahead") { if (value < 0 || value > 1) return bad(); c->run_ahead = (uint32_t)value; }
+    else if (n == "pace") { if (value < 0 || value > 1) return bad(); c->pace = value; }
     else if (n == "tile_order") {
         if (value < 0 || value > 1) return bad();
         if (value != c->tile_sort) for (int j = 0; j < prt_ctx::MAX_SUB; ++j) c->have_order[j] = false;      // (setting it again keeps a measured order)

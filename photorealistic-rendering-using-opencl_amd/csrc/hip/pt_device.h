@@ -1389,17 +1389,21 @@ PT_DEV void lane_init(Lane& L) {
 // `laggards`: some lane of the wave still owes frames of this launch.  Then, in a launch that allows it (FrameArgs::run_ahead:
 // "N spp" mode, where a pixel's result does not depend on how many frames the others have done), a lane that has done its
 // n_frames starts further segments instead of idling -- frame numbers and seeds are its own, so its path is the same path.
-PT_DEV bool lane_owes_frames(const FrameArgs& fa, const Lane& L) {
-    if (L.stage != ST_READY || L.begun) return L.f < fa.n_frames;
+// `target`: the frames this lane owes the launch -- fa.n_frames, or more for a pixel whose paths are longer than the frame's average ("N spp"
+// launches, FrameArgs::pace_inv_ref: render_kernel)
+PT_DEV bool lane_owes_frames(const FrameArgs& fa, const Lane& L, const unsigned target) {
+    if (L.stage != ST_READY || L.begun) return L.f < target;
     if (fa.spp_limit && L.reset && L.samples >= fa.spp_limit) return false;
-    return L.f < fa.n_frames;
+    return L.f < target;
 }
-PT_DEV bool lane_runnable(const FrameArgs& fa, const Lane& L, const bool laggards) {
+PT_DEV bool lane_owes_frames(const FrameArgs& fa, const Lane& L) { return lane_owes_frames(fa, L, fa.n_frames); }
+PT_DEV bool lane_runnable(const FrameArgs& fa, const Lane& L, const bool laggards, const unsigned target) {
     if (L.stage != ST_READY) return false;
     if (L.begun) return true;
     if (fa.spp_limit && L.reset && L.samples >= fa.spp_limit) return false;
-    return L.f < fa.n_frames || (fa.run_ahead && laggards && L.f < fa.seed_frames);
+    return L.f < target || (fa.run_ahead && laggards && L.f < fa.seed_frames);
 }
+PT_DEV bool lane_runnable(const FrameArgs& fa, const Lane& L, const bool laggards) { return lane_runnable(fa, L, laggards, fa.n_frames); }
 
 // E (also reached straight from A by lanes that need no walk): the end of radiance() and of render_kernel.
 // `surface`: handleSurface sampled a direction (base.cl:183-191 still to do); `lit`: the shadow ray was unoccluded.

@@ -137,6 +137,10 @@ struct FrameArgs {
     uint32_t seed_frames;                   // >= n_frames: frames from first_frame on that have seeds
     uint32_t run_ahead;                     // "N spp" launches: a lane that has done its n_frames goes on (up to seed_frames) for as long
                                             // as its wave waits for other lanes; how far it got is kept per pixel (DevState::q4.w >> 2)
+    float pace_inv_ref;                     // "N spp" launches with run_ahead: 0, or 1 / (the frame's mean path length so far).  A pixel whose own mean
+                                            // path length is longer owes the launches proportionally more than n_frames frames each (cumulatively; up to 2 x, within the seed
+                                            // table): it needs proportionally more frames for its samples, and what it does not do while the chip is full
+                                            // it does in the tail of the render, alone (DESIGN.md s4 "Round 4: the tail").  Schedule only: no bit depends on it
     uint32_t spp_limit;
     unsigned long long* unfinished;         // device counter: pixels not yet frozen (spp mode), or null
     unsigned long long* unfinished_host;    // null: the host reads `unfinished` itself.  Else `unfinished` is a pair {count, waves

@@ -99,6 +99,7 @@ __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene 
 
     Lane L;
     lane_init(L);
+    unsigned target = fa.n_frames;                              // frames this lane owes the launch
     if (!in_frame) { L.f = 0xffffffffu; L.reset = true; L.samples = 0xffffffffu; L.wasSpecular = false; }   // owes no frame, starts none
     else {
         const float4 a = S.q0[id], b = S.q1[id], c = S.q2[id], d = S.q3[id];
@@ -112,6 +113,12 @@ __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene 
         L.trans = e.z & 0xffffu; L.scatters = e.z >> 16;
         L.wasSpecular = (e.w & 1u) != 0; L.reset = (e.w & 2u) != 0;
         L.f = fa.run_ahead ? e.w >> 2 : 0u;                     // frames of this launch done in an earlier one ("N spp" launches only)
+        // the pace of this pixel: its own mean path length so far (segments / paths started) over the frame's (FrameArgs::pace_inv_ref)
+        if (fa.pace_inv_ref > 0.0f && e.x >= 8u) {
+            // (cumulative: after this launch the pixel should have done pace x the frames of the launches so far; its lead L.f counts towards that)
+            const float pace = fminf(fmaxf(d.w / (float)e.x * fa.pace_inv_ref, 1.0f), 3.0f);
+            target = min(fa.n_frames + (unsigned)((pace - 1.0f) * (float)(fa.first_frame - 1u + fa.n_frames)), fa.seed_frames);
+        }
     }
     extern __shared__ unsigned lds_stack[];                     // sc.stack_levels x PT_BLOCK, sized by the launch
     TravStack stk;
@@ -129,7 +136,7 @@ __global__ __launch_bounds__(PT_BLOCK, WAVES) void render_kernel(const DevScene 
     unsigned long long done_lanes_ = 0;
 #endif
     for (;;) {
-        const bool runnable = lane_runnable(fa, L, __any(lane_owes_frames(fa, L)));
+        const bool runnable = lane_runnable(fa, L, __any(lane_owes_frames(fa, L, target)), target);
         if (!__any(runnable || L.stage != ST_READY)) break;     // every lane has done its frames (or is frozen)
         if (ORDER) ++iterations;
         PT_CLK(7);
