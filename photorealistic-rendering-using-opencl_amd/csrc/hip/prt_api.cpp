@@ -489,19 +489,21 @@ extern "C" int prt_render_spp(prt_ctx* c, uint32_t spp, uint32_t max_frames, con
     uint32_t f = 0;
     unsigned long long unfinished = 1;
     float pace_inv_ref = 0.0f;                     // 1 / (the frame's mean path length): known once the first launch has retired
+    // (through a big tree the launches are 4 096 frames and a render is a handful of them: 871 k triangles, 3840x2160 x 2 048 spp 4.35 without, 4.31 with)
+    const bool pacing = c->pace && c->run_ahead && c->sc.n_pairs <= 65536u;
     if (K == 1) {
         while (f < max_frames && unfinished) {
             const uint32_t n = (max_frames - f < step) ? max_frames - f : step;
             HIPCHK(c, hipMemsetAsync(c->d_counters, 0, sizeof(unsigned long long), c->stream));
             FrameArgs fa = frame_args(c, 1 + f, n, c->d_seeds + 2 * (size_t)f, spp, true);
             fa.seed_frames = max_frames - f; fa.run_ahead = c->run_ahead;
-            fa.pace_inv_ref = (c->pace && c->run_ahead) ? pace_inv_ref : 0.0f;
+            fa.pace_inv_ref = pacing ? pace_inv_ref : 0.0f;
             c->last = launch_render(c->sc, c->cam, c->S, fa, c->fb, c->stream, c->lo);
             ++c->stats.launches;
             f += n;
             HIPCHK(c, hipMemcpyAsync(&unfinished, c->d_counters, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
-            if (c->pace && c->run_ahead && pace_inv_ref == 0.0f && unfinished) pace_inv_ref = inverse_mean_path_length(c, spp, c->stream);
+            if (pacing && pace_inv_ref == 0.0f && unfinished) pace_inv_ref = inverse_mean_path_length(c, spp, c->stream);
         }
     } else {
         // Every sub-part advances on its own stream until its own pixels are frozen.  The last wave of a launch writes
@@ -542,7 +544,7 @@ extern "C" int prt_render_spp(prt_ctx* c, uint32_t spp, uint32_t max_frames, con
                     const uint32_t n = (max_frames - fj[j] < step) ? max_frames - fj[j] : step;
                     FrameArgs fa = frame_args(c, 1 + fj[j], n, c->d_seeds + 2 * (size_t)fj[j], spp, true);
                     fa.seed_frames = max_frames - fj[j]; fa.run_ahead = c->run_ahead;
-                    fa.pace_inv_ref = (c->pace && c->run_ahead) ? pace_inv_ref : 0.0f;
+                    fa.pace_inv_ref = pacing ? pace_inv_ref : 0.0f;
                     fa.unfinished = c->d_counters + 4 + 2 * j;
                     fa.unfinished_host = c->h_unfinished + 2 * j + slot;
                     if (c->test_drop_report) fa.unfinished_host = c->h_unfinished + 2 * prt_ctx::MAX_SUB;     // (tests: the report goes astray)
@@ -590,7 +592,7 @@ extern "C" int prt_render_spp(prt_ctx* c, uint32_t spp, uint32_t max_frames, con
                         c->have_order[j] = true;
                     }
                     // the frame's mean path length, once per render (this sub-part's stream is idle: its launch has just retired)
-                    if (c->pace && c->run_ahead && pace_inv_ref == 0.0f && left) pace_inv_ref = inverse_mean_path_length(c, spp, c->sub_stream[j]);
+                    if (pacing && pace_inv_ref == 0.0f && left) pace_inv_ref = inverse_mean_path_length(c, spp, c->sub_stream[j]);
                     ++retired[j];
                     progressed = true;
                     if (!stop[j]) {

@@ -684,6 +684,28 @@ def test_expensive_tiles_first_is_invisible(prt, oracle, monkeypatch):
         assert out[k][2:] == out[0][2:] and out[k][4] == W * H
 
 
+def test_pacing_is_invisible(prt, oracle):
+    """prt_render_spp with "pace" (default on): from the second launch on a pixel whose own mean path length exceeds the frame's owes the
+    launches proportionally more frames, so that the pixels with long paths are not left for the tail of the render.  A pixel's frame numbers
+    and seeds are its own, so this is a schedule like any other: many short launches (the pace engages from the second one), samples-per-pixel
+    mode, rough dielectric (the config whose per-pixel path lengths differ most) -- with and without, the same bits, and fewer launches with."""
+    W, H, spp = 320, 200, 24
+    scene, cfg, cam, env, r = _setup(prt, "cornell_roughdiel", W, H)
+    seeds = prt.seed_pairs(spp * 40 + 64)
+    out = []
+    for pace in (0, 1):
+        r.set_option("pace", pace)
+        r.set_option("frames_per_launch", 16)
+        r.reset()
+        r.render_spp(spp, seeds)
+        c = r.counts(spp)
+        out.append((r.read_state(), r.read_framebuffer(), c.segments, c.samples, c.finished_pixels, r.stats().launches))
+    r.close()
+    _assert_same(oracle, out[0][0], out[0][1], out[1][0], out[1][1], "pace on vs off")
+    assert out[0][2:5] == out[1][2:5] and out[0][4] == W * H
+    assert out[1][5] < out[0][5], (out[0][5], out[1][5])          # the paced render needs fewer launches: nobody is left for a tail
+
+
 def test_a_launch_that_does_not_report_aborts_the_render(prt):
     """prt_render_spp arms a pinned word with ~0 before every launch of a sub-part and the last wave of the launch overwrites it with the
     number of unfinished pixels (render_kernel).  A report that never arrives (faked: option "test_drop_report" points the kernel at a spare
@@ -756,7 +778,7 @@ def test_options_are_validated(prt):
     scene = prt.HostScene("cornell_diffuse.json")
     r = prt.Renderer(scene.config(), device=0)
     assert r.kernel_variant() == ""
-    for name, value in (("waves", 4), ("waves", 7), ("scatter", 2), ("generic", 2), ("any_dist", 2), ("tri_q", 17), ("frames_per_launch", -1), ("tile_order", 2), ("test_drop_report", 2), ("pix_per_wave", 48), ("pool", 2), ("no_such_option", 1)):
+    for name, value in (("waves", 4), ("waves", 7), ("scatter", 2), ("generic", 2), ("any_dist", 2), ("tri_q", 17), ("frames_per_launch", -1), ("tile_order", 2), ("test_drop_report", 2), ("pix_per_wave", 48), ("pool", 2), ("pace", 2), ("no_such_option", 1)):
         with pytest.raises(prt.PrtError):
             r.set_option(name, value)
     r.close()
